@@ -1,0 +1,305 @@
+"""CPU oracle for the ESN OFDM/MIMO detector hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a float64 NumPy restatement of the reference algorithm
+(aoschu/esn-ofdm-mimo @ 2025-09-12).  It is NOT part of the product: only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it, and only as the checker / the timed CPU baseline.
+The product path (``esn_ofdm_mimo_amd``) never imports it and fails loudly if
+the HIP library is missing.
+
+Parity pin: every function below is checked against golden vectors produced by
+importing the reference's own ``libs/pyESN.py`` / ``libs/helper_mimo_esn_generic.py``
+/ ``libs/HelpFunc.py`` in the build container (``tests/golden/make_golden.py``,
+fixtures in ``tests/golden/*.npz``; see ``tests/test_oracle_golden.py``).
+
+Reference citations (file:line are relative to the reference tree):
+  * weight draw order .......... libs/pyESN.py:93-109
+  * state update ............... libs/pyESN.py:111-125
+  * input/teacher scaling ...... libs/pyESN.py:127-152
+  * fit (harvest + pinv) ....... libs/pyESN.py:154-216
+  * predict .................... libs/pyESN.py:218-255
+  * frame<->ESN adapter ........ libs/helper_mimo_esn_generic.py:5-86
+  * rx packing at inference .... system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:433-436
+  * output reconstruction ...... system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:47-58
+  * FFT + power de-scale ....... system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:439-441
+  * constellation .............. system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:17-28
+  * hard decision + bit labels . system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:30-32,95-103
+  * error counting ............. system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:451-456
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+__all__ = [
+    "broadcast_arg", "draw_weights", "OracleESN", "pack_delay_io",
+    "train_mimo_esn", "pack_rx", "outputs_to_time_signals", "time_to_freq",
+    "unit_qam", "bit_labels_lsb_first", "hard_bits", "count_bit_errors",
+    "detect_frame",
+]
+
+
+# --------------------------------------------------------------------------
+# a1: argument broadcasting (pyESN.py:4-24)
+# --------------------------------------------------------------------------
+def broadcast_arg(value, n):
+    """None stays None, a scalar becomes a length-n vector, a 1-D vector must
+    already have length n, anything else is rejected (pyESN.py:15-24)."""
+    if value is None:
+        return None
+    arr = np.array(value)
+    if arr.ndim == 0:
+        return np.array([arr] * n)
+    if arr.ndim == 1:
+        if len(arr) != n:
+            raise ValueError("arg must have length " + str(n))
+        return arr
+    raise ValueError("Invalid argument")
+
+
+# --------------------------------------------------------------------------
+# a3: weight initialisation (pyESN.py:93-109) -- draw ORDER is the contract
+# --------------------------------------------------------------------------
+def draw_weights(rng, n_in, n_out, n_res, spectral_radius, sparsity):
+    """Returns (W, W_in, W_fb) exactly as the reference draws them:
+    uniform(-.5,.5) dense matrix, a second uniform draw masks entries below
+    ``sparsity`` to 0, rescale to the requested spectral radius with LAPACK
+    eigvals, then W_in and W_fb uniform(-1,1)."""
+    w = rng.rand(n_res, n_res) - 0.5
+    mask = rng.rand(n_res, n_res) < sparsity
+    w[mask] = 0
+    rho = np.max(np.abs(np.linalg.eigvals(w)))
+    w = w * (spectral_radius / rho)
+    w_in = rng.rand(n_res, n_in) * 2 - 1
+    w_fb = rng.rand(n_res, n_out) * 2 - 1
+    return w, w_in, w_fb
+
+
+class OracleESN:
+    """float64 restatement of the reference ``ESN`` (pyESN.py:31-255).
+
+    Only the identity output activation is restated (no driver uses another).
+    ``feedback_scaling`` is accepted and ignored, as in the reference
+    (pyESN.py:35 -- never stored)."""
+
+    def __init__(self, n_inputs, n_outputs, n_reservoir=200,
+                 spectral_radius=0.95, sparsity=0, noise=0.001,
+                 input_shift=None, input_scaling=None, teacher_forcing=True,
+                 feedback_scaling=None, teacher_scaling=None,
+                 teacher_shift=None, random_state=None):
+        self.n_inputs, self.n_outputs, self.n_reservoir = n_inputs, n_outputs, n_reservoir
+        self.spectral_radius, self.sparsity, self.noise = spectral_radius, sparsity, noise
+        self.input_shift = broadcast_arg(input_shift, n_inputs)
+        self.input_scaling = broadcast_arg(input_scaling, n_inputs)
+        self.teacher_scaling, self.teacher_shift = teacher_scaling, teacher_shift
+        self.teacher_forcing = teacher_forcing
+        # pyESN.py:79-87: RandomState instance | truthy seed | global RNG
+        if isinstance(random_state, np.random.RandomState):
+            self.rng = random_state
+        elif random_state:
+            try:
+                self.rng = np.random.RandomState(random_state)
+            except TypeError as e:
+                raise Exception("Invalid seed: " + str(e))
+        else:
+            self.rng = np.random.mtrand._rand
+        self.W, self.W_in, self.W_feedb = draw_weights(
+            self.rng, n_inputs, n_outputs, n_reservoir, spectral_radius, sparsity)
+
+    # a4 ------------------------------------------------------------------
+    def scale_inputs(self, u):
+        if self.input_scaling is not None:
+            u = np.dot(u, np.diag(self.input_scaling))
+        if self.input_shift is not None:
+            u = u + self.input_shift
+        return u
+
+    def scale_teacher(self, d):
+        if self.teacher_scaling is not None:
+            d = d * self.teacher_scaling
+        if self.teacher_shift is not None:
+            d = d + self.teacher_shift
+        return d
+
+    def unscale_teacher(self, y):
+        if self.teacher_shift is not None:
+            y = y - self.teacher_shift
+        if self.teacher_scaling is not None:
+            y = y / self.teacher_scaling
+        return y
+
+    # a5 ------------------------------------------------------------------
+    def step(self, x, u, y_prev):
+        """tanh(W x + W_in u [+ W_fb y_prev]) + noise*(U(0,1)-0.5)  (pyESN.py:111-125).
+        The uniform draw happens on every call, noise or not."""
+        pre = self.W @ x + self.W_in @ u
+        if self.teacher_forcing:
+            pre = pre + self.W_feedb @ y_prev
+        return np.tanh(pre) + self.noise * (self.rng.rand(self.n_reservoir) - 0.5)
+
+    # a6 ------------------------------------------------------------------
+    def fit(self, inputs, outputs, transient=0):
+        inputs = np.asarray(inputs)
+        outputs = np.asarray(outputs)
+        if inputs.ndim < 2:
+            inputs = inputs.reshape(len(inputs), -1)
+        if outputs.ndim < 2:
+            outputs = outputs.reshape(len(outputs), -1)
+        u = self.scale_inputs(inputs)
+        d = self.scale_teacher(outputs)
+        n = inputs.shape[0]
+        states = np.zeros((n, self.n_reservoir))
+        for t in range(1, n):                      # row 0 is never fed (pyESN.py:180)
+            states[t] = self.step(states[t - 1], u[t], d[t - 1])
+        ext = np.hstack((states, u))
+        self.W_out = (np.linalg.pinv(ext[transient:]) @ d[transient:]).T
+        self.laststate = states[-1]
+        self.lastinput = inputs[-1]               # stored UNscaled (pyESN.py:196)
+        self.lastoutput = d[-1]
+        self._ext_states = ext                    # kept for tests (not in the reference)
+        return self.unscale_teacher(ext @ self.W_out.T)
+
+    # a7 ------------------------------------------------------------------
+    def predict(self, inputs, transient=0, continuation=True):
+        inputs = np.asarray(inputs)
+        if inputs.ndim < 2:
+            inputs = inputs.reshape(len(inputs), -1)
+        n = inputs.shape[0]
+        if continuation:
+            x, y = self.laststate, self.lastoutput
+        else:
+            x, y = np.zeros(self.n_reservoir), np.zeros(self.n_outputs)
+        u = self.scale_inputs(inputs)
+        out = np.zeros((n, self.n_outputs))
+        for t in range(n):                         # every row IS fed (pyESN.py:249-253)
+            x = self.step(x, u[t], y)
+            y = self.W_out @ np.concatenate([x, u[t]])
+            out[t] = y
+        return self.unscale_teacher(out[transient:])
+
+
+# --------------------------------------------------------------------------
+# a8: generic MIMO frame <-> ESN adapter (helper_mimo_esn_generic.py:5-86)
+# --------------------------------------------------------------------------
+def pack_delay_io(y_cp, x_cp, d, n_sub, cp_len, n_t, n_r):
+    """Interleave Re/Im of the received (input) and transmitted (teacher) pilot
+    into real matrices with output delay d (helper:26-38)."""
+    t = n_sub + cp_len
+    x_in = np.zeros((t + d, 2 * n_r))
+    x_out = np.zeros((t + d, 2 * n_t))
+    x_in[:t, 0::2] = y_cp.real
+    x_in[:t, 1::2] = y_cp.imag
+    x_out[d:d + t, 0::2] = x_cp.real
+    x_out[d:d + t, 1::2] = x_cp.imag
+    return x_in, x_out
+
+
+def _helper_nmse(pred, x_cp, d, n_sub, n_t, isi):
+    """The (mis-aligned) NMSE the helper reports (helper:47-55)."""
+    s = 0.0
+    for tx in range(n_t):
+        xh = pred[d:d + n_sub + 1, 2 * tx] + 1j * pred[d:d + n_sub + 1, 2 * tx + 1]
+        xt = x_cp[isi - 1:, tx]
+        m = min(len(xh), len(xt))
+        if m > 0:
+            s += np.linalg.norm(xh[:m] - xt[:m]) ** 2 / (np.linalg.norm(xt[:m]) ** 2 + 1e-12)
+    return s
+
+
+def train_mimo_esn(esn, delay_flag, min_delay, max_delay, cp_len, n_sub, n_t,
+                   n_r, isi, y_cp, x_cp):
+    """Restates trainMIMOESN_generic: fit -> predict -> (scan) -> final fit and
+    the 9-element return list (helper:58-86)."""
+    def trial(d):
+        x_in, x_out = pack_delay_io(y_cp, x_cp, d, n_sub, cp_len, n_t, n_r)
+        forget = d + cp_len
+        esn.fit(x_in, x_out, forget)
+        pred = esn.predict(x_in, forget, continuation=False)
+        return _helper_nmse(pred, x_cp, d, n_sub, n_t, isi), x_in, x_out, forget
+
+    if delay_flag == 0:
+        d = int((min_delay + max_delay) // 2)
+        nmse, x_in, x_out, forget = trial(d)
+        idx = d - min_delay
+    else:
+        best = None
+        nmse = 1e9
+        idx = 0
+        for dd in range(min_delay, max_delay + 1):
+            v, a, b, f = trial(dd)
+            if v < nmse:
+                nmse, best, idx = v, (a, b, f, dd), dd - min_delay
+        x_in, x_out, forget, d = best
+    esn.fit(x_in, x_out, forget)
+    delay = np.full(2 * n_t, int(d), dtype=int)
+    return [x_in, x_out, esn, delay, idx, int(d), int(d), forget, float(nmse)]
+
+
+# --------------------------------------------------------------------------
+# a9 - a12: the detector tail around predict
+# --------------------------------------------------------------------------
+def pack_rx(y_cp, delay_max):
+    """complex [T x N_r] -> real [T+delay_max x 2 N_r] (driver:433-436)."""
+    t, n_r = y_cp.shape
+    out = np.zeros((t + delay_max, 2 * n_r))
+    out[:t, 0::2] = y_cp.real
+    out[:t, 1::2] = y_cp.imag
+    return out
+
+
+def outputs_to_time_signals(y, delay, delay_min, n_sub, n_t):
+    """Per-tx complex sequences from the ESN outputs (driver:47-58)."""
+    seqs = []
+    for tx in range(n_t):
+        s_re = delay[2 * tx] - delay_min
+        s_im = delay[2 * tx + 1] - delay_min
+        seqs.append(y[s_re:s_re + n_sub, 2 * tx] + 1j * y[s_im:s_im + n_sub, 2 * tx + 1])
+    return seqs
+
+
+def time_to_freq(seqs, n_sub, p_i):
+    """(1/N) FFT / sqrt(Pi) per tx (driver:439-441)."""
+    out = np.zeros((n_sub, len(seqs)), dtype=complex)
+    for tx, s in enumerate(seqs):
+        out[:, tx] = (1.0 / n_sub) * np.fft.fft(s) / math.sqrt(p_i)
+    return out
+
+
+def unit_qam(bits_per_sym):
+    """Unit-mean-power square QAM; index = i*sqrt(M)+j has Re = pam[i],
+    Im = pam[j] (driver:17-28)."""
+    side = math.ceil(math.sqrt(2 ** bits_per_sym) / 2) * 2
+    pam = np.arange(-(side - 1), side, 2).astype(float)
+    re, im = np.meshgrid(pam, pam, indexing="ij")
+    c = (re + 1j * im).reshape(-1)
+    return c / math.sqrt(np.mean(np.abs(c) ** 2))
+
+
+def bit_labels_lsb_first(m):
+    """labels[idx, b] = bit b of idx (natural binary, LSB first; driver:30-32,60-64)."""
+    idx = np.arange(2 ** m)
+    return ((idx[:, None] >> np.arange(m)[None, :]) & 1).astype(int)
+
+
+def hard_bits(x_hat, const, m):
+    """Nearest-constellation-point bits, [N*m x N_t] (driver:95-103)."""
+    n, n_t = x_hat.shape
+    idx = np.argmin(np.abs(x_hat[:, :, None] - const[None, None, :]), axis=2)
+    labels = bit_labels_lsb_first(m)
+    bits = labels[idx]                       # [N, N_t, m]
+    return bits.transpose(0, 2, 1).reshape(n * m, n_t)
+
+
+def count_bit_errors(tx_bits, rx_bits):
+    return int(np.sum(tx_bits != rx_bits))
+
+
+def detect_frame(esn, y_cp, delay, delay_min, delay_max, forget, n_sub, n_t,
+                 p_i, const, m):
+    """predict + a9..a12 for one data frame: returns (X_hat [N x N_t], bits)."""
+    u = pack_rx(y_cp, delay_max)
+    y = esn.predict(u, forget, continuation=False)
+    seqs = outputs_to_time_signals(y, delay, delay_min, n_sub, n_t)
+    x_hat = time_to_freq(seqs, n_sub, p_i)
+    return x_hat, hard_bits(x_hat, const, m)

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (where /root/reference exists):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's own ``libs/pyESN.py``, ``libs/helper_mimo_esn_generic.py``
+and ``libs/HelpFunc.py`` (nothing is copied), drives them with seeded synthetic
+inputs and stores inputs + the reference's outputs as small .npz fixtures.
+Weights are not stored: they are re-drawn from the seed (RandomState draw order
+is part of the contract) and only pinned by digest + corner samples.
+
+Cases:
+  tiny   N_res=8    n_in=3  n_out=2  T=12
+  c2     N_res=100  SISO  n_in=2  n_out=2  T=512  transient 0  (fit/predict continuation=True)
+  c3     N_res=100  2x2   N=512 CP=7 d=3  (helper)
+  c4     N_res=512  4x8   N=128 CP=7 d=3  (helper + 16-frame detection batch)
+  c4s    N_res=300  4x8   N=128           (driver default reservoir)
+  c5     N_res=2048 4x8   N=128           (helper, W_out only + predictions)
+"""
+import hashlib
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/libs")
+
+import numpy as np  # noqa: E402
+
+import pyESN as ref_pyesn  # noqa: E402  (the reference)
+from helper_mimo_esn_generic import trainMIMOESN_generic as ref_train  # noqa: E402
+from HelpFunc import HelpFunc as RefHelp  # noqa: E402
+
+from oracle.ofdm_frames import LinkConfig, make_frame, tdlb_mimo_taps, exp_pdp_taps  # noqa: E402
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+def weight_pins(esn):
+    out = {}
+    for name in ("W", "W_in", "W_feedb"):
+        a = getattr(esn, name)
+        out[name + "_sha"] = digest(a)
+        out[name + "_head"] = a.ravel()[:4].copy()
+        out[name + "_tail"] = a.ravel()[-4:].copy()
+    out["rho"] = np.max(np.abs(np.linalg.eigvals(esn.W)))
+    return out
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"{name}.npz  {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def make_ref(n_in, n_out, n_res, seed, noise, **kw):
+    return ref_pyesn.ESN(n_inputs=n_in, n_outputs=n_out, n_reservoir=n_res,
+                         noise=noise, random_state=seed, **kw)
+
+
+def case_plain(name, n_in, n_out, n_res, t_len, seed, transient, kw, t_pred=None):
+    """G1-G5: init digests, fit (noise 0 and 0.001), predict both continuation modes."""
+    rs = np.random.RandomState(seed + 7)
+    u = rs.randn(t_len, n_in)
+    d = np.tanh(rs.randn(t_len, n_out) * 0.5)
+    u2 = rs.randn(t_pred or t_len, n_in)
+    out = dict(seed=seed, transient=transient, u=u, d=d, u2=u2)
+    for tag, noise in (("n0", 0.0), ("n1", 0.001)):
+        esn = make_ref(n_in, n_out, n_res, seed, noise, **kw)
+        if tag == "n0":
+            out.update(weight_pins(esn))
+        out[tag + "_pred_train"] = esn.fit(u, d, transient)
+        out[tag + "_W_out"] = esn.W_out.copy()
+        out[tag + "_laststate"] = esn.laststate.copy()
+        out[tag + "_lastoutput"] = esn.lastoutput.copy()
+        out[tag + "_pred_cont"] = esn.predict(u2, 0, continuation=True)
+        out[tag + "_pred_fresh"] = esn.predict(u2, transient, continuation=False)
+    save(name, **out)
+
+
+def case_helper(name, cfg, n_res, seed, ebno_db, channel_kind, n_frames, store_frames=True):
+    """G6/G7: trainMIMOESN_generic on a synthetic pilot, then predict on data frames."""
+    rs = np.random.RandomState(seed + 11)
+    if channel_kind == "tdlb":
+        taps = tdlb_mimo_taps(cfg, seed + 1234)
+    else:
+        taps = exp_pdp_taps(cfg, rs)
+    pilot = make_frame(cfg, ebno_db, taps, rs)
+    n_in, n_out = 2 * cfg.n_r, 2 * cfg.n_t
+    kw = dict(spectral_radius=0.9, sparsity=0.1,
+              input_shift=np.zeros(n_in),
+              input_scaling=cfg.input_scaling(ebno_db) * np.ones(n_in),
+              teacher_scaling=cfg.teacher_scale * np.ones(n_out),
+              teacher_shift=np.zeros(n_out),
+              feedback_scaling=np.zeros(n_out))
+    out = dict(seed=seed, ebno_db=ebno_db, taps=taps,
+               pilot_y=pilot["y_cp"], pilot_x=pilot["x_cp"])
+    for tag, noise in (("n0", 0.0), ("n1", 0.001)):
+        esn = make_ref(n_in, n_out, n_res, seed, noise, **kw)
+        if tag == "n0":
+            out.update(weight_pins(esn))
+        ret = ref_train(esn, 0, cfg.min_delay, cfg.max_delay, cfg.cp, cfg.n_sub,
+                        cfg.n_t, cfg.n_r, cfg.isi, pilot["y_cp"], pilot["x_cp"])
+        esn_in, esn_out, esn, delay, d_idx, d_min, d_max, forget, nmse = ret
+        out[tag + "_W_out"] = esn.W_out.copy()
+        out[tag + "_laststate"] = esn.laststate.copy()
+        out[tag + "_nmse"] = nmse
+        if tag == "n0":
+            out.update(esn_in=esn_in, esn_out=esn_out, delay=delay, d_idx=d_idx,
+                       d_min=d_min, d_max=d_max, forget=forget)
+            # data frames through the trained (noise=0) ESN
+            rs2 = np.random.RandomState(seed + 13)
+            ys, bits, preds = [], [], []
+            for _ in range(n_frames):
+                fr = make_frame(cfg, ebno_db, taps, rs2)
+                u = np.zeros((cfg.n_sub + d_max + cfg.cp, n_in))
+                for rx in range(cfg.n_r):
+                    u[:, 2 * rx] = np.r_[fr["y_cp"][:, rx].real, np.zeros(d_max)]
+                    u[:, 2 * rx + 1] = np.r_[fr["y_cp"][:, rx].imag, np.zeros(d_max)]
+                preds.append(esn.predict(u, forget, continuation=False))
+                ys.append(fr["y_cp"])
+                bits.append(fr["bits"])
+            if store_frames:
+                out["data_y"] = np.array(ys)
+            out["data_bits"] = np.packbits(np.array(bits).astype(np.uint8))
+            out["data_bits_shape"] = np.array(np.array(bits).shape)
+            out["data_pred"] = np.array(preds)
+            out["data_seed"] = seed + 13
+    save(name, **out)
+
+
+def case_constellation():
+    out = {}
+    for m in (2, 4, 6):
+        out[f"qam{m}"] = RefHelp.UnitQamConstellation(m)
+    save("constellation", **out)
+
+
+def case_misc():
+    """G5/G8: teacher_forcing=False, scalar scalings, 1-D input, error cases."""
+    rs = np.random.RandomState(5)
+    u = rs.randn(40)
+    d = np.sin(np.arange(40) * 0.3)
+    out = dict(u=u, d=d)
+    esn = ref_pyesn.ESN(1, 1, n_reservoir=20, spectral_radius=0.8, sparsity=0.2, noise=0.0,
+                        input_scaling=0.5, input_shift=0.1, teacher_scaling=0.7,
+                        teacher_shift=-0.2, teacher_forcing=False, random_state=99)
+    out["nofb_pred_train"] = esn.fit(u, d, 3)
+    out["nofb_W_out"] = esn.W_out.copy()
+    out["nofb_pred"] = esn.predict(u[:17], 2, continuation=True)
+    esn = ref_pyesn.ESN(1, 1, n_reservoir=20, spectral_radius=1.1, noise=0.0, random_state=3)
+    out["plain_pred_train"] = esn.fit(u, d)
+    out["plain_pred"] = esn.predict(u[:9])
+    # correct_dimensions error cases
+    errs = []
+    for bad in ([1.0, 2.0], np.zeros((2, 2))):
+        try:
+            ref_pyesn.ESN(3, 1, input_scaling=bad)
+            errs.append("")
+        except ValueError as e:
+            errs.append(str(e))
+    out["err_msgs"] = np.array(errs)
+    out["cd_scalar"] = ref_pyesn.correct_dimensions(2.5, 4)
+    save("misc", **out)
+
+
+def main():
+    case_constellation()
+    case_misc()
+    case_plain("tiny", 3, 2, 8, 12, seed=42, transient=2,
+               kw=dict(spectral_radius=0.9, sparsity=0.25, input_scaling=[0.3, 0.2, 0.1],
+                       input_shift=[0.0, 0.1, -0.1], teacher_scaling=0.5, teacher_shift=0.05))
+    case_plain("c2", 2, 2, 100, 512, seed=7, transient=0,
+               kw=dict(spectral_radius=0.9, sparsity=0.1, input_scaling=0.05 * np.ones(2),
+                       input_shift=np.zeros(2), teacher_scaling=5e-3 * np.ones(2),
+                       teacher_shift=np.zeros(2)), t_pred=64)
+    c3 = LinkConfig(n_t=2, n_r=2, n_sub=512)
+    case_helper("c3", c3, 100, seed=21, ebno_db=12, channel_kind="exp", n_frames=2)
+    c4 = LinkConfig()
+    case_helper("c4", c4, 512, seed=31, ebno_db=12, channel_kind="tdlb", n_frames=16)
+    case_helper("c4s", c4, 300, seed=33, ebno_db=18, channel_kind="tdlb", n_frames=2)
+    case_helper("c5", c4, 2048, seed=35, ebno_db=12, channel_kind="tdlb", n_frames=1)
+
+
+if __name__ == "__main__":
+    main()
