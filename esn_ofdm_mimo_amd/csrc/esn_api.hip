@@ -1,0 +1,242 @@
+// C ABI entry points (include/esn_hip.h): argument validation, geometry choice,
+// kernel launches.  No allocation, no synchronisation, no global state besides
+// the thread-local error string -- every call is capturable into a hipGraph.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "esn_common.h"
+
+namespace esn {
+// esn_recur_f64.hip
+int launch_recur_f64(const RecurParams& p, hipStream_t stream);
+size_t recur_f64_lds_bytes(int FB, int n_res, int n_in, int n_out);
+// esn_recur_mfma.hip
+bool mfma_geometry(int precision, int n_res, int n_in, int n_out, Geometry* g);
+int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
+// esn_pack.hip
+size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
+size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
+int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g, const double* W,
+                        const double* Win, const double* Wfb, void* packed, hipStream_t stream);
+int launch_pack_readout(int precision, const esn_shape_t* sh, const Geometry& g, int n_groups,
+                        const double* Wout, void* packed, hipStream_t stream);
+// esn_solve.hip
+size_t solve_work_doubles(int rows, int cols, int n_out);
+int launch_readout_solve(const double* E, const double* D, int n_groups, int T, int transient,
+                         int cols, int n_out, const double* t_scale, const double* t_shift,
+                         double* W_out, int* status, void* workspace, hipStream_t stream);
+// esn_detect.hip
+int launch_detect_count(const DetectParams& dp, hipStream_t stream);
+}  // namespace esn
+
+using namespace esn;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(int e, const char* what) {
+    if (e == 0) return 0;
+    if (e > 0) return fail(-1000 - e, "%s: HIP error %d (%s)", what, e, hipGetErrorString((hipError_t)e));
+    return fail(-2, "%s: no kernel instance for this shape", what);
+}
+
+static bool check_shape(const esn_shape_t* s) {
+    return s && s->n_res > 0 && s->n_in > 0 && s->n_out > 0 && s->n_wsets > 0;
+}
+
+// Geometry for a precision; for ESN_F64 only Bt (frames per tile) is meaningful.
+static bool geometry_for(int precision, const esn_shape_t* s, Geometry* g) {
+    memset(g, 0, sizeof(*g));
+    if (precision == ESN_F64) {
+        int fb = 8;
+        while (fb > 1 && recur_f64_lds_bytes(fb, s->n_res, s->n_in, s->n_out) > 150 * 1024) fb >>= 1;
+        if (recur_f64_lds_bytes(fb, s->n_res, s->n_in, s->n_out) > 160 * 1024) return false;
+        g->Bt = fb;
+        return true;
+    }
+    if (precision < ESN_F64 || precision > ESN_BF16) return false;
+    return mfma_geometry(precision, s->n_res, s->n_in, s->n_out, g);
+}
+
+extern "C" {
+
+const char* esn_last_error(void) { return g_err; }
+
+int esn_abi_version(void) { return 1; }
+
+int esn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail((int)e, "hipGetDevice");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return hip_fail((int)e, "hipGetDeviceProperties");
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, prop.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return 0;
+}
+
+int esn_tile_frames(int precision, const esn_shape_t* shape) {
+    Geometry g;
+    if (!check_shape(shape)) return fail(-1, "esn_tile_frames: invalid shape");
+    if (!geometry_for(precision, shape, &g)) return fail(-2, "esn_tile_frames: unsupported shape/precision");
+    return g.Bt;
+}
+
+size_t esn_packed_weights_bytes(int precision, const esn_shape_t* shape) {
+    Geometry g;
+    if (!check_shape(shape) || !geometry_for(precision, shape, &g)) return 0;
+    return packed_w_bytes(precision, shape->n_res, shape->n_in, shape->n_out, g);
+}
+
+size_t esn_packed_readout_bytes(int precision, const esn_shape_t* shape) {
+    Geometry g;
+    if (!check_shape(shape) || !geometry_for(precision, shape, &g)) return 0;
+    return packed_wout_bytes(precision, shape->n_res, shape->n_in, shape->n_out, g);
+}
+
+int esn_pack_weights(int precision, const esn_shape_t* shape, const double* W, const double* W_in,
+                     const double* W_fb, void* packed, void* stream) {
+    Geometry g;
+    if (!check_shape(shape)) return fail(-1, "esn_pack_weights: invalid shape");
+    if (!W || !W_in || !W_fb || !packed) return fail(-1, "esn_pack_weights: null pointer");
+    if (!geometry_for(precision, shape, &g)) return fail(-2, "esn_pack_weights: unsupported shape/precision");
+    return hip_fail(launch_pack_weights(precision, shape, g, W, W_in, W_fb, packed, (hipStream_t)stream),
+                    "esn_pack_weights");
+}
+
+int esn_pack_readout(int precision, const esn_shape_t* shape, int n_groups, const double* W_out,
+                     void* packed, void* stream) {
+    Geometry g;
+    if (!check_shape(shape) || n_groups <= 0) return fail(-1, "esn_pack_readout: invalid shape");
+    if (!W_out || !packed) return fail(-1, "esn_pack_readout: null pointer");
+    if (!geometry_for(precision, shape, &g)) return fail(-2, "esn_pack_readout: unsupported shape/precision");
+    return hip_fail(launch_pack_readout(precision, shape, g, n_groups, W_out, packed, (hipStream_t)stream),
+                    "esn_pack_readout");
+}
+
+static int fill_common(RecurParams& p, int precision, const esn_shape_t* shape, const char* who) {
+    memset(&p, 0, sizeof(p));
+    if (!check_shape(shape)) return fail(-1, "%s: invalid shape", who);
+    if (!geometry_for(precision, shape, &p.g)) return fail(-2, "%s: unsupported shape/precision", who);
+    p.n_res = shape->n_res; p.n_in = shape->n_in; p.n_out = shape->n_out;
+    p.teacher_forcing = shape->teacher_forcing ? 1 : 0;
+    p.n_wsets = shape->n_wsets;
+    p.wset_stride = packed_w_bytes(precision, p.n_res, p.n_in, p.n_out, p.g);
+    p.wout_stride = packed_wout_bytes(precision, p.n_res, p.n_in, p.n_out, p.g);
+    return 0;
+}
+
+int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packed_w, const void* packed_wout,
+                      const double* in_scale, const double* in_shift, const double* t_scale,
+                      const double* t_shift, const double* U, int n_frames, int frames_per_group, int T_in,
+                      int T, int transient, const double* x0, const double* y0, double noise, int noise_mode,
+                      const double* noise_u, uint64_t seed, double* Y, void* stream) {
+    RecurParams p;
+    int rc = fill_common(p, precision, shape, "esn_predict_batch");
+    if (rc) return rc;
+    if (!packed_w || !packed_wout || !U || !Y) return fail(-1, "esn_predict_batch: null pointer");
+    if (n_frames <= 0 || frames_per_group <= 0 || T <= 0 || T_in < 0 || T_in > T || transient < 0 || transient >= T)
+        return fail(-1, "esn_predict_batch: invalid sizes (n_frames=%d F=%d T_in=%d T=%d transient=%d)",
+                    n_frames, frames_per_group, T_in, T, transient);
+    if (noise_mode == ESN_NOISE_TENSOR && !noise_u) return fail(-1, "esn_predict_batch: noise tensor missing");
+    if (noise_mode < ESN_NOISE_NONE || noise_mode > ESN_NOISE_COUNTER) return fail(-1, "esn_predict_batch: bad noise mode");
+    p.n_frames = n_frames;
+    p.frames_per_pgroup = frames_per_group;
+    p.frames_per_tgroup = frames_per_group;
+    p.tiles_per_tgroup = (frames_per_group + p.g.Bt - 1) / p.g.Bt;
+    const int n_groups = (n_frames + frames_per_group - 1) / frames_per_group;
+    p.n_tiles = n_groups * p.tiles_per_tgroup;
+    p.T_in = T_in; p.S = T; p.in_row_off = 0; p.transient = transient; p.harvest = 0;
+    p.packed_w = packed_w; p.packed_wout = packed_wout;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
+    p.U = U; p.x0 = x0; p.y0 = y0; p.noise_u = noise_u;
+    p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
+    p.Y = Y;
+    int e = (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
+                                   : launch_recur_mfma(precision, p, (hipStream_t)stream);
+    return hip_fail(e, "esn_predict_batch");
+}
+
+int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
+                      const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
+                      const double* D, int n_groups, int T, double noise, int noise_mode, const double* noise_u,
+                      uint64_t seed, double* E, void* stream) {
+    RecurParams p;
+    int rc = fill_common(p, precision, shape, "esn_harvest_batch");
+    if (rc) return rc;
+    if (precision != ESN_F64 && precision != ESN_F32)
+        return fail(-2, "esn_harvest_batch: states are harvested in float64 or float32 only");
+    if (!packed_w || !U || !D || !E) return fail(-1, "esn_harvest_batch: null pointer");
+    if (n_groups <= 0 || T < 2) return fail(-1, "esn_harvest_batch: invalid sizes (n_groups=%d T=%d)", n_groups, T);
+    if (noise_mode == ESN_NOISE_TENSOR && !noise_u) return fail(-1, "esn_harvest_batch: noise tensor missing");
+    if (noise_mode < ESN_NOISE_NONE || noise_mode > ESN_NOISE_COUNTER) return fail(-1, "esn_harvest_batch: bad noise mode");
+    p.n_frames = n_groups;
+    p.frames_per_pgroup = 1;
+    if (p.n_wsets == 1) {            // shared reservoir: tiles span groups
+        p.frames_per_tgroup = n_groups;
+        p.tiles_per_tgroup = (n_groups + p.g.Bt - 1) / p.g.Bt;
+        p.n_tiles = p.tiles_per_tgroup;
+    } else {                          // one weight set per sequence
+        p.frames_per_tgroup = 1;
+        p.tiles_per_tgroup = 1;
+        p.n_tiles = n_groups;
+    }
+    p.T_in = T; p.S = T - 1; p.in_row_off = 1; p.transient = 0; p.harvest = 1;
+    p.packed_w = packed_w;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
+    p.U = U; p.D = D; p.noise_u = noise_u;
+    p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
+    p.E = E;
+    int e = (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
+                                   : launch_recur_mfma(precision, p, (hipStream_t)stream);
+    return hip_fail(e, "esn_harvest_batch");
+}
+
+size_t esn_readout_solve_workspace_bytes(int n_groups, int rows, int cols, int n_out) {
+    if (n_groups <= 0 || rows <= 0 || cols <= 0 || n_out <= 0) return 0;
+    return sizeof(double) * solve_work_doubles(rows, cols, n_out) * (size_t)n_groups;
+}
+
+int esn_readout_solve_batch(const double* E, const double* D, int n_groups, int T, int transient, int cols,
+                            int n_out, const double* t_scale, const double* t_shift, double* W_out,
+                            int* status, void* workspace, void* stream) {
+    if (!E || !D || !W_out || !status || !workspace) return fail(-1, "esn_readout_solve_batch: null pointer");
+    if (n_groups <= 0 || T <= 0 || transient < 0 || transient >= T || cols <= 0 || n_out <= 0)
+        return fail(-1, "esn_readout_solve_batch: invalid sizes");
+    return hip_fail(launch_readout_solve(E, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
+                                         status, workspace, (hipStream_t)stream),
+                    "esn_readout_solve_batch");
+}
+
+int esn_detect_count(const double* Y, int n_frames, int frames_per_group, int n_sub, int n_t, int bits_per_sym,
+                     const double* p_i, const uint8_t* tx_bits, long long* err_count, long long* bit_count,
+                     double* X_hat, void* stream) {
+    if (!Y || !p_i || !tx_bits || !err_count || !bit_count) return fail(-1, "esn_detect_count: null pointer");
+    if (n_frames <= 0 || frames_per_group <= 0 || n_t <= 0) return fail(-1, "esn_detect_count: invalid sizes");
+    int log2n = 0;
+    while ((1 << log2n) < n_sub) ++log2n;
+    if ((1 << log2n) != n_sub || n_sub < 2 || n_sub > 2048)
+        return fail(-1, "esn_detect_count: N=%d must be a power of two in [2, 2048]", n_sub);
+    if (bits_per_sym < 2 || bits_per_sym > 10 || (bits_per_sym & 1))
+        return fail(-1, "esn_detect_count: bits_per_sym=%d must be even (square QAM)", bits_per_sym);
+    DetectParams dp;
+    dp.Y = Y; dp.n_frames = n_frames; dp.frames_per_group = frames_per_group; dp.n_sub = n_sub;
+    dp.log2n = log2n; dp.n_t = n_t; dp.m = bits_per_sym; dp.p_i = p_i; dp.tx_bits = tx_bits;
+    dp.err = err_count; dp.bits = bit_count; dp.X_hat = X_hat;
+    return hip_fail(launch_detect_count(dp, (hipStream_t)stream), "esn_detect_count");
+}
+
+}  // extern "C"

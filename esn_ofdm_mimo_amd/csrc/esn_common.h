@@ -1,0 +1,101 @@
+// Shared host/device definitions for the ESN hot-path kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/esn_hip.h"
+
+namespace esn {
+
+// Padded geometry of one recurrence problem.  The GEMM of one timestep is
+//   P[Mp x Bt] = Wext[Mp x Kp] * Z[Kp x Bt],   Z = [X ; U ; F]
+// with the state rows at k in [0,Mp), the (scaled) inputs at [kin, kin+n_in)
+// and the fed-back output / teacher at [kfb, kfb+n_out).
+struct Geometry {
+    int Mp;     // n_res rounded up to the row tiling of the kernel
+    int kin;    // == Mp
+    int kfb;    // kin + round4(n_in)
+    int Kp;     // total K, multiple of 32
+    int Ks;     // LDS row stride in elements (Kp + conflict-avoidance pad)
+    int Bt;     // frames per workgroup tile
+    int NW, MT, NT;  // waves, row tiles / wave, column tiles / wave (MFMA kernels)
+};
+
+struct RecurParams {
+    int n_res, n_in, n_out, teacher_forcing;
+    Geometry g;
+    int n_frames;          // total sequences
+    int frames_per_pgroup; // parameter group (W_out, scalings, x0/y0) = frame / this
+    int frames_per_tgroup; // tiles never straddle a multiple of this
+    int tiles_per_tgroup;
+    int n_wsets;
+    int T_in;              // valid input rows per frame
+    int S;                 // recurrence steps
+    int in_row_off;        // input row fed at step s is s + in_row_off (harvest: 1)
+    int transient;
+    int harvest;           // 1: teacher feedback, write E; 0: own-output feedback, write Y
+    int n_tiles;
+    const void* packed_w;   size_t wset_stride;   // bytes per weight set
+    const void* packed_wout; size_t wout_stride;  // bytes per group
+    const double* in_scale; const double* in_shift;
+    const double* t_scale;  const double* t_shift;
+    const double* U; const double* D;
+    const double* x0; const double* y0;
+    const double* noise_u;
+    double noise; int noise_mode; uint64_t seed;
+    double* Y; double* E;
+};
+
+struct DetectParams {
+    const double* Y; int n_frames, frames_per_group, n_sub, log2n, n_t, m;
+    const double* p_i; const uint8_t* tx_bits;
+    long long* err; long long* bits; double* X_hat;
+};
+
+inline __host__ __device__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Bijective XCD-aware remap (guide T1): consecutive logical tiles land on the
+// same XCD so tiles of one weight set share that XCD's L2.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    if (nwg < nx) return bid;
+    int q = nwg / nx, r = nwg % nx, x = bid % nx, i = bid / nx;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// Counter-based uniform in [0,1): two 16-bit samples per 32-bit hash.  Keyed by
+// (seed, frame, step) once per column, then one integer mix per pair of rows.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t noise_key(uint64_t seed, uint32_t frame, uint32_t step) {
+    uint32_t k = mix32((uint32_t)seed ^ (frame * 0x9E3779B9U));
+    k = mix32(k ^ (uint32_t)(seed >> 32) ^ (step * 0x85EBCA6BU + 0x27d4eb2fU));
+    return k;
+}
+// uniform sample for reservoir row `row` under key `k`, in [0,1) with 16-bit resolution
+__device__ __forceinline__ float noise_uniform(uint32_t k, uint32_t row) {
+    uint32_t h = mix32(k + (row >> 1) * 0x9E3779B9U);
+    uint32_t v = (row & 1) ? (h >> 16) : (h & 0xffffU);
+    return (float)v * (1.0f / 65536.0f) + (0.5f / 65536.0f);
+}
+
+// float32 tanh: odd Taylor polynomial below 0.3 (truncation < 2e-9 relative),
+// 1 - 2/(exp(2|x|)+1) above; both evaluated, selected per lane (no divergence).
+__device__ __forceinline__ float tanh_f32(float x) {
+    float ax = fabsf(x);
+    float x2 = x * x;
+    float p = -0.00886323552990220f;            // -1382/155925
+    p = fmaf(p, x2, 0.0218694885361552f);      //  62/2835
+    p = fmaf(p, x2, -0.0539682539682540f);     // -17/315
+    p = fmaf(p, x2, 0.133333333333333f);       //  2/15
+    p = fmaf(p, x2, -0.333333333333333f);      // -1/3
+    p = fmaf(p * x2, x, x);
+    float e = __expf(2.0f * ax);                // v_exp_f32 path
+    float r = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    r = copysignf(r, x);
+    return ax < 0.3f ? p : r;
+}
+
+}  // namespace esn

@@ -1,0 +1,183 @@
+// Weight packing: float64 row-major reference matrices (pyESN.py:93-109,191-192)
+// -> device images in the exact order the recurrence kernels consume them.
+#include "esn_common.h"
+
+namespace esn {
+
+// Wext[row][k] of the padded GEMM (see Geometry): W | W_in | W_fb with zero padding.
+__device__ __forceinline__ double wext(const double* W, const double* Win, const double* Wfb,
+                                       int n_res, int n_in, int n_out, int tf,
+                                       int kin, int kfb, int row, int k) {
+    if (row >= n_res) return 0.0;
+    if (k < n_res) return W[(size_t)row * n_res + k];
+    if (k >= kin && k < kin + n_in) return Win[(size_t)row * n_in + (k - kin)];
+    if (tf && k >= kfb && k < kfb + n_out) return Wfb[(size_t)row * n_out + (k - kfb)];
+    return 0.0;
+}
+
+// float64 image: K-major Wk[k][n_res], k over [W | W_in | W_fb] without padding.
+__global__ void pack_w_f64_kernel(const double* W, const double* Win, const double* Wfb,
+                                  int n_res, int n_in, int n_out, int tf, int n_wsets,
+                                  double* out) {
+    const size_t K = (size_t)n_res + n_in + n_out;
+    const size_t per = K * n_res;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per * n_wsets;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t ws = i / per, j = i % per;
+        int k = (int)(j / n_res), r = (int)(j % n_res);
+        const double* w = W + ws * (size_t)n_res * n_res;
+        const double* wi = Win + ws * (size_t)n_res * n_in;
+        const double* wf = Wfb + ws * (size_t)n_res * n_out;
+        double v;
+        if (k < n_res) v = w[(size_t)r * n_res + k];
+        else if (k < n_res + n_in) v = wi[(size_t)r * n_in + (k - n_res)];
+        else v = tf ? wf[(size_t)r * n_out + (k - n_res - n_in)] : 0.0;
+        out[i] = v;
+    }
+}
+
+// MFMA image: [row tile rt][32-byte k-group kg][lane][16 bytes]; lane (r,h) holds
+// elements k = (32 kg + 16 h)/ES + j of row 32 rt + r.
+template <typename T>
+__global__ void pack_w_mfma_kernel(const double* W, const double* Win, const double* Wfb,
+                                   int n_res, int n_in, int n_out, int tf, int n_wsets,
+                                   Geometry g, T* out) {
+    constexpr int ES = sizeof(T);
+    constexpr int EPL = 16 / ES;                       // elements per lane per group
+    const int nkg = g.Kp * ES / 32;
+    const size_t per = (size_t)(g.Mp / 32) * nkg * 64 * EPL;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per * n_wsets;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t ws = i / per, j = i % per;
+        int e = (int)(j % EPL); j /= EPL;
+        int lane = (int)(j % 64); j /= 64;
+        int kg = (int)(j % nkg);
+        int rt = (int)(j / nkg);
+        int row = rt * 32 + (lane & 31);
+        int k = (kg * 32 + 16 * (lane >> 5)) / ES + e;
+        double v = wext(W + ws * (size_t)n_res * n_res, Win + ws * (size_t)n_res * n_in,
+                        Wfb + ws * (size_t)n_res * n_out, n_res, n_in, n_out, tf, g.kin, g.kfb, row, k);
+        out[i] = (T)(float)v;
+    }
+}
+
+// Readout image for the 16x16 MFMA: [part][ot][64-byte k-group][lane][16 B] then a
+// 16-byte trailer {1/gain, gain, 0, 0} (float).  gain is a power of two that brings
+// max|W_out| of the group to ~2^10 so fp16 images keep full precision; part 1 holds
+// the rounding residual of part 0 (fp16/bf16 only).
+template <typename T, int PARTS>
+__global__ __launch_bounds__(256) void pack_wout_mfma_kernel(const double* Wout, int n_res, int n_in,
+                                                              int n_out, Geometry g, size_t stride_bytes,
+                                                              char* out_base) {
+    constexpr int ES = sizeof(T);
+    constexpr int EPL = 16 / ES;
+    __shared__ double red[256];
+    const int grp = blockIdx.x;
+    const int ncols = n_res + n_in;
+    const double* wo = Wout + (size_t)grp * n_out * ncols;
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n_out * ncols; i += blockDim.x) m = fmax(m, fabs(wo[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    m = red[0];
+    double gain = 1.0;
+    if (ES == 2 && m > 0.0 && isfinite(m)) {
+        int ex;
+        frexp(m, &ex);                 // m = f * 2^ex, f in [0.5,1)
+        gain = ldexp(1.0, 10 - ex);    // m*gain in [2^9, 2^10)
+    }
+    const int n_ot = (n_out + 15) / 16;
+    const int nkg64 = g.Kp * ES / 64;
+    char* out = out_base + (size_t)grp * stride_bytes;
+    T* img = reinterpret_cast<T*>(out);
+    const size_t per_part = (size_t)n_ot * nkg64 * 64 * EPL;
+    for (size_t i = threadIdx.x; i < per_part; i += blockDim.x) {
+        size_t j = i;
+        int e = (int)(j % EPL); j /= EPL;
+        int lane = (int)(j % 64); j /= 64;
+        int kg = (int)(j % nkg64);
+        int ot = (int)(j / nkg64);
+        int o = ot * 16 + (lane & 15);
+        int k = (kg * 64 + 16 * (lane >> 4)) / ES + e;
+        double v = 0.0;
+        if (o < n_out) {
+            if (k < n_res) v = wo[(size_t)o * ncols + k];
+            else if (k >= g.kin && k < g.kin + n_in) v = wo[(size_t)o * ncols + n_res + (k - g.kin)];
+        }
+        v *= gain;
+        T hi = (T)(float)v;
+        img[i] = hi;
+        if (PARTS == 2) img[per_part + i] = (T)(float)(v - (double)(float)hi);
+    }
+    if (threadIdx.x == 0) {
+        float* tr = reinterpret_cast<float*>(out + PARTS * per_part * ES);
+        tr[0] = (float)(1.0 / gain); tr[1] = (float)gain; tr[2] = 0.f; tr[3] = 0.f;
+    }
+}
+
+size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g) {
+    if (precision == ESN_F64) return sizeof(double) * (size_t)(n_res + n_in + n_out) * n_res;
+    const int es = (precision == ESN_F32) ? 4 : 2;
+    return (size_t)g.Mp * g.Kp * es;
+}
+
+size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g) {
+    if (precision == ESN_F64) return sizeof(double) * (size_t)n_out * (n_res + n_in);
+    const int es = (precision == ESN_F32) ? 4 : 2;
+    const int parts = (precision == ESN_F32) ? 1 : 2;
+    const int n_ot = (n_out + 15) / 16;
+    return (size_t)parts * n_ot * 16 * g.Kp * es + 16;
+}
+
+int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g, const double* W,
+                        const double* Win, const double* Wfb, void* packed, hipStream_t stream) {
+    const int blocks = 1024, threads = 256;
+    if (precision == ESN_F64) {
+        hipLaunchKernelGGL(pack_w_f64_kernel, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
+                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets,
+                           reinterpret_cast<double*>(packed));
+    } else if (precision == ESN_F32) {
+        hipLaunchKernelGGL(pack_w_mfma_kernel<float>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
+                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g,
+                           reinterpret_cast<float*>(packed));
+    } else if (precision == ESN_F16) {
+        hipLaunchKernelGGL(pack_w_mfma_kernel<_Float16>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
+                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g,
+                           reinterpret_cast<_Float16*>(packed));
+    } else if (precision == ESN_BF16) {
+        hipLaunchKernelGGL(pack_w_mfma_kernel<__bf16>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
+                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g,
+                           reinterpret_cast<__bf16*>(packed));
+    } else {
+        return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_pack_readout(int precision, const esn_shape_t* sh, const Geometry& g, int n_groups,
+                        const double* Wout, void* packed, hipStream_t stream) {
+    const size_t stride = packed_wout_bytes(precision, sh->n_res, sh->n_in, sh->n_out, g);
+    if (precision == ESN_F64) {
+        hipError_t e = hipMemcpyAsync(packed, Wout, stride * n_groups, hipMemcpyDeviceToDevice, stream);
+        return (int)e;
+    }
+    char* out = reinterpret_cast<char*>(packed);
+    if (precision == ESN_F32)
+        hipLaunchKernelGGL((pack_wout_mfma_kernel<float, 1>), dim3(n_groups), dim3(256), 0, stream, Wout,
+                           sh->n_res, sh->n_in, sh->n_out, g, stride, out);
+    else if (precision == ESN_F16)
+        hipLaunchKernelGGL((pack_wout_mfma_kernel<_Float16, 2>), dim3(n_groups), dim3(256), 0, stream, Wout,
+                           sh->n_res, sh->n_in, sh->n_out, g, stride, out);
+    else if (precision == ESN_BF16)
+        hipLaunchKernelGGL((pack_wout_mfma_kernel<__bf16, 2>), dim3(n_groups), dim3(256), 0, stream, Wout,
+                           sh->n_res, sh->n_in, sh->n_out, g, stride, out);
+    else
+        return -1;
+    return (int)hipGetLastError();
+}
+
+}  // namespace esn

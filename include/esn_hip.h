@@ -1,0 +1,165 @@
+/* esn_hip.h -- C ABI of the MI355X-native ESN OFDM/MIMO detector hot path.
+ *
+ * Shared library: esn_ofdm_mimo_amd/libesn_hip.so (built by __graft_entry__.build()).
+ * Every entry point is extern "C", takes plain pointers and sizes, returns an int
+ * status (0 = ok, <0 = error; text via esn_last_error()) and launches its work
+ * on the caller's hipStream_t (passed as void*; NULL = default stream).  No
+ * hidden global state besides a thread-local error string; no exceptions cross
+ * the boundary.  All array arguments are DEVICE pointers unless a name ends in
+ * `_host`.  Arrays keep the reference's own row-major float64 layouts so a
+ * binding needs no repacking:
+ *
+ *   inputs   U  [B][T_in][n_in]     (== complex128 [B][T_in][N_r] viewed as float64
+ *                                    with Re/Im interleaved: the packing of
+ *                                    Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:433-436 and
+ *                                    helper_mimo_esn_generic.py:30-33 is a VIEW; the
+ *                                    d trailing zero rows are synthesised: T > T_in)
+ *   outputs  Y  [B][T-transient][n_out]  (== complex128 [B][N][N_t] view, :47-58)
+ *
+ * Reference interface each entry point replaces (paths relative to the
+ * reference tree, libs/pyESN.py unless noted):
+ *
+ *   esn_pack_weights        ESN.initweights result W/W_in/W_feedb (:93-109) ->
+ *                           device-resident, MFMA-fragment-ordered copy.
+ *   esn_pack_readout        W_out of ESN.fit (:191-192) -> fragment-ordered copy.
+ *   esn_predict_batch       ESN.predict (:218-255) incl. _scale_inputs (:127-135),
+ *                           _update (:111-125), readout (:252), _unscale_teacher
+ *                           (:146-152); batched over B frames in G groups.
+ *   esn_harvest_batch       state-harvest loop of ESN.fit (:176-182,189) ->
+ *                           extended states [states, inputs_scaled].
+ *   esn_readout_solve_batch pinv solve of ESN.fit (:191-192).
+ *   esn_detect_count        driver tail: reconstruct (:47-58 of the 4x8 driver),
+ *                           (1/N) FFT / sqrt(Pi) (:439-441), hard decision
+ *                           (:95-103), bit-error count (:451-456).
+ */
+#ifndef ESN_HIP_H
+#define ESN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Arithmetic of the recurrence. */
+enum esn_precision {
+    ESN_F64 = 0,   /* float64 FMA on the vector ALU: reference arithmetic        */
+    ESN_F32 = 1,   /* v_mfma_f32_32x32x2_f32: exact float32 products + accumulate */
+    ESN_F16 = 2,   /* v_mfma_f32_32x32x16_f16: fp16 operands, float32 accumulate  */
+    ESN_BF16 = 3   /* v_mfma_f32_32x32x16_bf16: bf16 operands, float32 accumulate */
+};
+
+/* State-noise source (pyESN.py:124-125: + noise * (U[0,1) - 0.5)). */
+enum esn_noise_mode {
+    ESN_NOISE_NONE = 0,     /* noise == 0                                             */
+    ESN_NOISE_TENSOR = 1,   /* caller supplies the uniforms [B][S][n_res] (parity)     */
+    ESN_NOISE_COUNTER = 2   /* counter-based generator keyed (seed, frame, step, row)  */
+};
+
+/* Geometry shared by the recurrence entry points. */
+typedef struct esn_shape {
+    int n_res;            /* reservoir size                                          */
+    int n_in;             /* input units  (2 N_r)                                    */
+    int n_out;            /* output units (2 N_t)                                    */
+    int teacher_forcing;  /* 1: W_feedb term active (pyESN.py:117-120)               */
+    int n_wsets;          /* number of (W, W_in, W_feedb) sets: 1 = shared reservoir */
+} esn_shape_t;
+
+const char* esn_last_error(void);
+
+/* ABI version (bumped on any signature change). */
+int esn_abi_version(void);
+
+/* Device facts used for roofline reporting (any pointer may be NULL). */
+int esn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz,
+                    char* arch_name, int arch_name_len);
+
+/* Frames per workgroup tile the recurrence kernel uses for this shape and
+ * precision (>= 1); frames of one group are padded up to a multiple of it
+ * inside the kernel, never in the caller's arrays. */
+int esn_tile_frames(int precision, const esn_shape_t* shape);
+
+/* Bytes of the packed weight image for one weight set / one readout. */
+size_t esn_packed_weights_bytes(int precision, const esn_shape_t* shape);
+size_t esn_packed_readout_bytes(int precision, const esn_shape_t* shape);
+
+/* W [n_wsets][n_res][n_res], W_in [n_wsets][n_res][n_in], W_fb [n_wsets][n_res][n_out]
+ * (float64, row-major) -> packed [n_wsets][esn_packed_weights_bytes]. */
+int esn_pack_weights(int precision, const esn_shape_t* shape,
+                     const double* W, const double* W_in, const double* W_fb,
+                     void* packed, void* stream);
+
+/* W_out [n_groups][n_out][n_res+n_in] (float64) -> packed [n_groups][esn_packed_readout_bytes]. */
+int esn_pack_readout(int precision, const esn_shape_t* shape, int n_groups,
+                     const double* W_out, void* packed, void* stream);
+
+/* Batched ESN.predict.
+ *
+ * Frames are ordered by group: frame b belongs to group b / frames_per_group
+ * (its W_out, scalings, initial state) and, when shape->n_wsets > 1, to weight
+ * set (b / frames_per_group) % n_wsets.
+ *
+ *   packed_w      from esn_pack_weights            packed_wout  from esn_pack_readout
+ *   in_scale/in_shift   [n_groups][n_in]  or NULL (=1 / =0)        (pyESN.py:131-134)
+ *   t_scale/t_shift     [n_groups][n_out] or NULL                  (pyESN.py:140-151)
+ *   U             [B][T_in][n_in]; rows T_in..T-1 are zeros before scaling
+ *   x0, y0        [n_groups][n_res], [n_groups][n_out] start state and fed-back
+ *                 output (continuation=True: laststate/lastoutput, :234-237) or NULL (zeros)
+ *   noise_u       [B][T][n_res] uniforms when noise_mode == ESN_NOISE_TENSOR
+ *   Y             [B][T-transient][n_out], unscaled (:255)
+ */
+int esn_predict_batch(int precision, const esn_shape_t* shape,
+                      const void* packed_w, const void* packed_wout,
+                      const double* in_scale, const double* in_shift,
+                      const double* t_scale, const double* t_shift,
+                      const double* U, int n_frames, int frames_per_group,
+                      int T_in, int T, int transient,
+                      const double* x0, const double* y0,
+                      double noise, int noise_mode, const double* noise_u,
+                      uint64_t seed, double* Y, void* stream);
+
+/* Batched state harvest of ESN.fit: one training sequence per group.
+ *
+ *   U [n_groups][T][n_in], D [n_groups][T][n_out] (teacher, unscaled)
+ *   E [n_groups][T][n_res+n_in] = hstack(states, inputs_scaled) (:189); row 0 of
+ *   the states is zero and input row 0 is never fed (:179-182).
+ *   noise_u [n_groups][T-1][n_res] when noise_mode == ESN_NOISE_TENSOR.
+ */
+int esn_harvest_batch(int precision, const esn_shape_t* shape,
+                      const void* packed_w,
+                      const double* in_scale, const double* in_shift,
+                      const double* t_scale, const double* t_shift,
+                      const double* U, const double* D, int n_groups, int T,
+                      double noise, int noise_mode, const double* noise_u,
+                      uint64_t seed, double* E, void* stream);
+
+/* W_out[g] = (pinv(E[g][transient:]) @ (D[g][transient:]*t_scale + t_shift)).T  (:191-192)
+ *
+ * float64 Householder QR: of E^T when rows < cols (minimum-norm solution, what
+ * pinv returns for the under-determined 4x8 case) and of E otherwise.
+ *   workspace      esn_readout_solve_workspace_bytes(...) bytes of device memory
+ *   status [n_groups]  0 = ok, 1 = numerically rank deficient (|r_jj| <= 1e-13 max|r|;
+ *                  the dependent direction is dropped), written on device
+ */
+size_t esn_readout_solve_workspace_bytes(int n_groups, int rows, int cols, int n_out);
+int esn_readout_solve_batch(const double* E, const double* D, int n_groups, int T,
+                            int transient, int cols, int n_out,
+                            const double* t_scale, const double* t_shift,
+                            double* W_out, int* status, void* workspace, void* stream);
+
+/* Fused detector tail: Y [B][N][2 N_t] time-domain ESN outputs
+ * -> (1/N) FFT_N / sqrt(Pi[group]) -> nearest unit-power square-QAM point ->
+ * natural-binary LSB-first bits -> compare with tx_bits [B][N*m][N_t] (uint8) ->
+ * err_count[group] += mismatches, bit_count[group] += N*m*N_t  (int64, device).
+ * X_hat (complex128 [B][N][N_t] as float64 pairs) is optional (NULL to skip). */
+int esn_detect_count(const double* Y, int n_frames, int frames_per_group,
+                     int n_sub, int n_t, int bits_per_sym,
+                     const double* p_i, const uint8_t* tx_bits,
+                     long long* err_count, long long* bit_count,
+                     double* X_hat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESN_HIP_H */

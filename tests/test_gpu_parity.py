@@ -1,0 +1,270 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+reference-generated golden vectors.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (written per test):
+  f64 kernels  : 1e-9 relative to max|expected| (float64 round-off + LAPACK-vs-QR);
+  f32 MFMA     : 1e-5 relative (SURVEY section 4 tier 2);
+  f16/bf16 MFMA: 1e-2 relative AND >= 99.9 % identical hard-decision bits.
+"""
+import numpy as np
+import pytest
+
+from oracle import esn_oracle as eo
+from oracle.ofdm_frames import LinkConfig, make_frame, tdlb_mimo_taps
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, want):
+    return float(np.max(np.abs(got - want)) / (np.max(np.abs(want)) + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from esn_ofdm_mimo_amd import pyESN, helper_mimo_esn_generic, batched
+    return pyESN, helper_mimo_esn_generic, batched
+
+
+PLAIN = {
+    "tiny": dict(n_in=3, n_out=2, n_res=8,
+                 kw=dict(spectral_radius=0.9, sparsity=0.25, input_scaling=[0.3, 0.2, 0.1],
+                         input_shift=[0.0, 0.1, -0.1], teacher_scaling=0.5, teacher_shift=0.05)),
+    "c2": dict(n_in=2, n_out=2, n_res=100,
+               kw=dict(spectral_radius=0.9, sparsity=0.1, input_scaling=0.05 * np.ones(2),
+                       input_shift=np.zeros(2), teacher_scaling=5e-3 * np.ones(2),
+                       teacher_shift=np.zeros(2))),
+}
+
+
+@pytest.mark.parametrize("name", list(PLAIN))
+@pytest.mark.parametrize("tag,noise", [("n0", 0.0), ("n1", 0.001)])
+def test_dropin_fit_predict_vs_reference_golden(amd, golden, name, tag, noise):
+    """2-D drop-in: same seed -> same weights, same noise stream -> reference outputs."""
+    pyESN = amd[0]
+    g, c = golden(name), PLAIN[name]
+    tr = int(g["transient"])
+    esn = pyESN.ESN(c["n_in"], c["n_out"], c["n_res"], noise=noise, random_state=int(g["seed"]), **c["kw"])
+    pred_train = esn.fit(g["u"], g["d"], tr)
+    assert esn.fit_status == 0
+    assert rel_err(esn.laststate, g[tag + "_laststate"]) < 1e-11
+    np.testing.assert_allclose(esn.lastoutput, g[tag + "_lastoutput"], rtol=1e-13)
+    assert rel_err(pred_train, g[tag + "_pred_train"]) < 1e-8
+    assert rel_err(esn.W_out, g[tag + "_W_out"]) < 1e-6
+    assert rel_err(esn.predict(g["u2"], 0, continuation=True), g[tag + "_pred_cont"]) < 1e-8
+    assert rel_err(esn.predict(g["u2"], tr, continuation=False), g[tag + "_pred_fresh"]) < 1e-8
+
+
+def _helper_esn(mod, cfg, n_res, seed, ebno, noise, **extra):
+    n_in, n_out = 2 * cfg.n_r, 2 * cfg.n_t
+    return mod.ESN(n_in, n_out, n_res, spectral_radius=0.9, sparsity=0.1, noise=noise,
+                   input_shift=np.zeros(n_in), input_scaling=cfg.input_scaling(ebno) * np.ones(n_in),
+                   teacher_scaling=cfg.teacher_scale * np.ones(n_out), teacher_shift=np.zeros(n_out),
+                   feedback_scaling=np.zeros(n_out), random_state=seed, **extra)
+
+
+HELPER = {"c3": (LinkConfig(n_t=2, n_r=2, n_sub=512), 100), "c4": (LinkConfig(), 512), "c4s": (LinkConfig(), 300)}
+
+
+@pytest.mark.parametrize("name", list(HELPER))
+def test_helper_dropin_vs_reference_golden(amd, golden, name):
+    pyESN, helper, _ = amd
+    g = golden(name)
+    cfg, n_res = HELPER[name]
+    seed, ebno = int(g["seed"]), float(g["ebno_db"])
+    esn = _helper_esn(pyESN, cfg, n_res, seed, ebno, 0.0)
+    ret = helper.trainMIMOESN_generic(esn, 0, cfg.min_delay, cfg.max_delay, cfg.cp, cfg.n_sub, cfg.n_t,
+                                      cfg.n_r, cfg.isi, g["pilot_y"], g["pilot_x"])
+    x_in, x_out, esn2, delay, d_idx, d_min, d_max, forget, nmse = ret
+    assert esn2 is esn and len(ret) == 9
+    np.testing.assert_array_equal(x_in, g["esn_in"])
+    np.testing.assert_array_equal(x_out, g["esn_out"])
+    np.testing.assert_array_equal(delay, g["delay"])
+    assert (d_idx, d_min, d_max, forget) == (int(g["d_idx"]), int(g["d_min"]), int(g["d_max"]), int(g["forget"]))
+    assert rel_err(esn.laststate, g["n0_laststate"]) < 1e-10
+    assert nmse == pytest.approx(float(g["n0_nmse"]), rel=1e-4)
+    # W_out through its action on the reference-side extended states
+    oracle = eo.OracleESN(2 * cfg.n_r, 2 * cfg.n_t, n_res, spectral_radius=0.9, sparsity=0.1, noise=0.0,
+                          input_shift=np.zeros(2 * cfg.n_r),
+                          input_scaling=cfg.input_scaling(ebno) * np.ones(2 * cfg.n_r),
+                          teacher_scaling=cfg.teacher_scale * np.ones(2 * cfg.n_t),
+                          teacher_shift=np.zeros(2 * cfg.n_t), random_state=seed)
+    oracle.fit(x_in, x_out, forget)
+    ext = oracle._ext_states[forget:]
+    assert rel_err(ext @ esn.W_out.T, ext @ g["n0_W_out"].T) < 1e-7
+    # data frames: reference predictions with the reference's W_out
+    esn.W_out = g["n0_W_out"]
+    for y_cp, want in zip(g["data_y"], g["data_pred"]):
+        got = esn.predict(eo.pack_rx(y_cp, d_max), forget, continuation=False)
+        assert rel_err(got, want) < 1e-8
+
+
+def _c4_batch(golden, amd, precision, noise=0.0):
+    pyESN = amd[0]
+    g = golden("c4")
+    cfg, n_res = HELPER["c4"]
+    esn = _helper_esn(pyESN, cfg, n_res, int(g["seed"]), float(g["ebno_db"]), noise)
+    esn.W_out = g["n0_W_out"]
+    d = int(g["d_max"])
+    u = np.stack([eo.pack_rx(y, d) for y in g["data_y"]])
+    got = esn.predict(u, int(g["forget"]), continuation=False, precision=precision)
+    return g, cfg, got
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-8), ("f32", 1e-5), ("f16", 1e-2), ("bf16", 3e-2)])
+def test_batched_predict_c4_vs_reference_golden(amd, golden, precision, tol):
+    """16 frames of the 4x8 N_res=512 case in one launch vs the reference's own predictions."""
+    g, cfg, got = _c4_batch(golden, amd, precision)
+    want = g["data_pred"]
+    assert got.shape == want.shape
+    err = rel_err(got, want)
+    assert err < tol, (precision, err)
+    # hard decisions: identical bits on >= 99.9 % of positions
+    const = eo.unit_qam(cfg.m)
+    p_i = cfg.p_i(float(g["ebno_db"]))
+    same = tot = 0
+    for a, b in zip(got, want):
+        ba = eo.hard_bits(eo.time_to_freq(eo.outputs_to_time_signals(a, g["delay"], 0, cfg.n_sub, cfg.n_t), cfg.n_sub, p_i), const, cfg.m)
+        bb = eo.hard_bits(eo.time_to_freq(eo.outputs_to_time_signals(b, g["delay"], 0, cfg.n_sub, cfg.n_t), cfg.n_sub, p_i), const, cfg.m)
+        same += int(np.sum(ba == bb))
+        tot += ba.size
+    assert same / tot >= 0.999, (precision, same / tot)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32", "f16"])
+def test_ragged_batch_and_groups(amd, precision):
+    """3 groups x 37 frames (not a multiple of any tile), per-group W_out and scalings, short inputs
+    (T_in < T: zero rows synthesised) -- every frame must equal its own single-frame f64 result."""
+    _, _, batched = amd
+    rs = np.random.RandomState(3)
+    n_in, n_out, n_res, t_in, t, tr, G, F = 4, 2, 40, 20, 23, 3, 3, 37
+    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=0.0)
+    in_scale = rs.rand(G, n_in) + 0.5
+    in_shift = rs.randn(G, n_in) * 0.1
+    t_scale = rs.rand(G, n_out) + 0.5
+    t_shift = rs.randn(G, n_out) * 0.1
+    bank.set_scaling(in_scale, in_shift, t_scale, t_shift)
+    w_out = rs.randn(G, n_out, n_res + n_in) * 0.1
+    bank.set_readout(w_out)
+    u = rs.randn(G * F, t_in, n_in)
+    x0 = rs.randn(G, n_res) * 0.1
+    y0 = rs.randn(G, n_out) * 0.1
+    got = bank.predict(u, F, T=t, transient=tr, precision=precision, x0=x0, y0=y0).cpu().numpy()
+    assert got.shape == (G * F, t - tr, n_out)
+    tol = {"f64": 1e-10, "f32": 2e-5, "f16": 2e-2}[precision]
+    for b in (0, 1, 36, 37, 73, 74, 110):
+        grp = b // F
+        o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[grp], input_shift=in_shift[grp],
+                         teacher_scaling=t_scale[grp], teacher_shift=t_shift[grp], random_state=1)
+        o.W, o.W_in, o.W_feedb, o.W_out = w, w_in, w_fb, w_out[grp]
+        o.laststate, o.lastoutput = x0[grp], y0[grp]
+        upad = np.vstack([u[b], np.zeros((t - t_in, n_in))])
+        want = o.predict(upad, tr, continuation=True)
+        assert rel_err(got[b], want) < tol, (precision, b, rel_err(got[b], want))
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-11), ("f32", 1e-5)])
+def test_harvest_batch_shared_reservoir(amd, precision, tol):
+    """G pilots through one shared reservoir: E[g] equals the oracle's extended states."""
+    _, _, batched = amd
+    rs = np.random.RandomState(11)
+    n_in, n_out, n_res, t, G = 6, 4, 70, 33, 5
+    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=0.0)
+    in_scale, t_scale = rs.rand(G, n_in) + 0.5, rs.rand(G, n_out) + 0.5
+    bank.set_scaling(in_scale, None, t_scale, None)
+    u, d = rs.randn(G, t, n_in), rs.randn(G, t, n_out)
+    E = bank.harvest(u, d, precision=precision).cpu().numpy()
+    for g in range(G):
+        o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[g], teacher_scaling=t_scale[g],
+                         random_state=1)
+        o.W, o.W_in, o.W_feedb = w, w_in, w_fb
+        o.fit(u[g], d[g], 0)
+        assert rel_err(E[g], o._ext_states) < tol
+
+
+def test_per_group_reservoirs(amd):
+    """Reference-faithful mode: one (W, W_in, W_fb) per group, fit + predict against the oracle."""
+    _, _, batched = amd
+    rs = np.random.RandomState(5)
+    n_in, n_out, n_res, t, G, F = 4, 2, 48, 40, 3, 5
+    ws = [eo.draw_weights(np.random.RandomState(100 + g), n_in, n_out, n_res, 0.9, 0.2) for g in range(G)]
+    bank = batched.ReservoirBank(n_in, n_out, n_res, np.stack([w[0] for w in ws]), np.stack([w[1] for w in ws]),
+                                 np.stack([w[2] for w in ws]), noise=0.0)
+    u, d = rs.randn(G, t, n_in), rs.randn(G, t, n_out)
+    bank.fit(u, d, transient=4, precision="f64", noise_mode="none")
+    assert int(bank.fit_status.sum().item()) == 0
+    u2 = rs.randn(G * F, t, n_in)
+    got = bank.predict(u2, F, transient=2, precision="f32").cpu().numpy()
+    for g in range(G):
+        o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, random_state=1)
+        o.W, o.W_in, o.W_feedb = ws[g]
+        o.fit(u[g], d[g], 4)
+        assert rel_err(bank.W_out[g].cpu().numpy() @ o._ext_states[4:].T, o.W_out @ o._ext_states[4:].T) < 1e-8
+        o.W_out = bank.W_out[g].cpu().numpy()
+        for f in range(F):
+            want = o.predict(u2[g * F + f], 2, continuation=False)
+            assert rel_err(got[g * F + f], want) < 2e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(128, 528), (40, 40), (512, 104), (300, 90)])
+def test_readout_solve_vs_pinv(amd, rows, cols):
+    _, _, batched = amd
+    rs = np.random.RandomState(rows + cols)
+    G, n_out, tr = 3, 4, 5
+    bank = batched.ReservoirBank(cols - 2, n_out, 2, np.zeros((2, 2)), np.zeros((2, cols - 2)), np.zeros((2, n_out)))
+    E = rs.randn(G, rows + tr, cols)
+    E[:, :, :3] *= 1e-3                      # uneven column scales
+    D = rs.randn(G, rows + tr, n_out)
+    t_scale = rs.rand(G, n_out) + 0.5
+    bank.set_scaling(None, None, t_scale, None)
+    W, status = bank.solve(E, D, tr)
+    assert int(status.sum().item()) == 0
+    for g in range(G):
+        want = (np.linalg.pinv(E[g, tr:]) @ (D[g, tr:] * t_scale[g])).T
+        assert rel_err(W[g].cpu().numpy(), want) < 1e-9
+
+
+def test_detect_count_vs_oracle(amd, golden):
+    _, _, batched = amd
+    g = golden("c4")
+    cfg = LinkConfig()
+    bits = np.unpackbits(g["data_bits"])[:np.prod(g["data_bits_shape"])].reshape(g["data_bits_shape"])
+    pred = g["data_pred"]                                  # [16, 128, 8]
+    p_i = cfg.p_i(float(g["ebno_db"]))
+    bank = batched.ReservoirBank(2, 2, 2, np.zeros((2, 2)), np.zeros((2, 2)), np.zeros((2, 2)))
+    F = 8                                                  # two groups of 8 frames
+    err, nb, xh = bank.detect_count(pred, bits.astype(np.uint8), np.array([p_i, p_i]), F, cfg.n_sub, cfg.n_t,
+                                    cfg.m, want_xhat=True)
+    const = eo.unit_qam(cfg.m)
+    want_err = np.zeros(2, dtype=np.int64)
+    for i, (y, b) in enumerate(zip(pred, bits)):
+        x_hat = eo.time_to_freq(eo.outputs_to_time_signals(y, g["delay"], 0, cfg.n_sub, cfg.n_t), cfg.n_sub, p_i)
+        got_x = xh[i].cpu().numpy().view(np.complex128).reshape(cfg.n_sub, cfg.n_t)
+        assert rel_err(got_x, x_hat) < 1e-12
+        want_err[i // F] += eo.count_bit_errors(b, eo.hard_bits(x_hat, const, cfg.m))
+    np.testing.assert_array_equal(err.cpu().numpy(), want_err)        # integer work: bit-exact
+    np.testing.assert_array_equal(nb.cpu().numpy(), [F * cfg.n_sub * cfg.m * cfg.n_t] * 2)
+
+
+def test_counter_noise_statistics(amd):
+    """The counter generator is zero-mean uniform of width `noise`; outputs stay within the
+    perturbation the reference's own state noise causes (statistical, not bit-equal)."""
+    pyESN = amd[0]
+    rs = np.random.RandomState(2)
+    esn = pyESN.ESN(3, 2, n_reservoir=64, spectral_radius=0.5, noise=0.01, random_state=9)
+    esn.W_out = rs.randn(2, 67) * 0.0
+    esn.W_out[0, :64] = 1.0 / 64          # y0 = mean(state)
+    esn.W_out[1, 0] = 1.0                 # y1 = state[0]
+    u = np.zeros((512, 50, 3))
+    esn.teacher_forcing = False
+    esn._bank = None
+    y = esn.predict(u, 10, continuation=False, precision="f32", seed=123)
+    # with zero input and no feedback x = noise*(u-0.5) + tanh(W x_prev): |x| <~ noise
+    s = y[:, :, 1].ravel()
+    assert abs(s.mean()) < 3e-4
+    assert 0.8 * 0.01 / np.sqrt(12) < s.std() < 1.4 * 0.01 / np.sqrt(12)
+    y2 = esn.predict(u, 10, continuation=False, precision="f32", seed=123)
+    np.testing.assert_array_equal(y, y2)                 # same seed -> same stream
+    y3 = esn.predict(u, 10, continuation=False, precision="f32", seed=124)
+    assert np.abs(y3 - y).max() > 0
