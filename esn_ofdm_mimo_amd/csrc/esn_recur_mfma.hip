@@ -41,15 +41,19 @@ struct TraitsF32 {
     static __device__ __forceinline__ void mma32(f32x16& c, u32x4 a, u32x4 b) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[i]),
-                                                     __builtin_bit_cast(float, b[i]), c, 0, 0, 0);
+        {
+            const uint32_t ai = a[i], bi = b[i];   // copy out: bit_cast of a vector element lvalue reads lane 0
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(ai), __uint_as_float(bi), c, 0, 0, 0);
+        }
     }
     // 64-byte row group, lane quarter q takes 16 B: 4 x (16x16x4)
     static __device__ __forceinline__ void mma16(f32x4& c, u32x4 a, u32x4 b) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[i]),
-                                                     __builtin_bit_cast(float, b[i]), c, 0, 0, 0);
+        {
+            const uint32_t ai = a[i], bi = b[i];
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ai), __uint_as_float(bi), c, 0, 0, 0);
+        }
     }
     static __device__ __forceinline__ void store4(char* dst, float v0, float v1, float v2, float v3) {
         f32x4 v = {v0, v1, v2, v3};
