@@ -154,11 +154,13 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     if (noise_mode == ESN_NOISE_TENSOR && !noise_u) return fail(-1, "esn_predict_batch: noise tensor missing");
     if (noise_mode < ESN_NOISE_NONE || noise_mode > ESN_NOISE_COUNTER) return fail(-1, "esn_predict_batch: bad noise mode");
     p.n_frames = n_frames;
-    p.frames_per_pgroup = frames_per_group;
-    p.frames_per_tgroup = frames_per_group;
-    p.tiles_per_tgroup = (frames_per_group + p.g.Bt - 1) / p.g.Bt;
-    const int n_groups = (n_frames + frames_per_group - 1) / frames_per_group;
-    p.n_tiles = n_groups * p.tiles_per_tgroup;
+    p.F = frames_per_group;
+    p.n_groups = (n_frames + frames_per_group - 1) / frames_per_group;
+    // slots per group: whole tiles when each group has its own weight set, else the readout's
+    // 16-frame column granularity (MFMA kernels) or no padding at all (float64 kernel)
+    if (p.n_wsets > 1) p.Fpad = round_up(p.F, p.g.Bt);
+    else p.Fpad = (precision == ESN_F64) ? p.F : round_up(p.F, 16);
+    p.n_tiles = (int)(((long long)p.n_groups * p.Fpad + p.g.Bt - 1) / p.g.Bt);
     p.T_in = T_in; p.S = T; p.in_row_off = 0; p.transient = transient; p.harvest = 0;
     p.packed_w = packed_w; p.packed_wout = packed_wout;
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
@@ -184,16 +186,10 @@ int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packe
     if (noise_mode == ESN_NOISE_TENSOR && !noise_u) return fail(-1, "esn_harvest_batch: noise tensor missing");
     if (noise_mode < ESN_NOISE_NONE || noise_mode > ESN_NOISE_COUNTER) return fail(-1, "esn_harvest_batch: bad noise mode");
     p.n_frames = n_groups;
-    p.frames_per_pgroup = 1;
-    if (p.n_wsets == 1) {            // shared reservoir: tiles span groups
-        p.frames_per_tgroup = n_groups;
-        p.tiles_per_tgroup = (n_groups + p.g.Bt - 1) / p.g.Bt;
-        p.n_tiles = p.tiles_per_tgroup;
-    } else {                          // one weight set per sequence
-        p.frames_per_tgroup = 1;
-        p.tiles_per_tgroup = 1;
-        p.n_tiles = n_groups;
-    }
+    p.n_groups = n_groups;
+    p.F = 1;
+    p.Fpad = (p.n_wsets == 1) ? 1 : p.g.Bt;   // shared reservoir: tiles span groups
+    p.n_tiles = (int)(((long long)n_groups * p.Fpad + p.g.Bt - 1) / p.g.Bt);
     p.T_in = T; p.S = T - 1; p.in_row_off = 1; p.transient = 0; p.harvest = 1;
     p.packed_w = packed_w;
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;

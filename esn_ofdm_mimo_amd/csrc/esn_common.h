@@ -24,10 +24,14 @@ struct Geometry {
 struct RecurParams {
     int n_res, n_in, n_out, teacher_forcing;
     Geometry g;
+    // Frames are ordered by group (frame = grp*F + j).  Workgroup tiles are cut from a padded
+    // "slot" axis: slot = grp*Fpad + j, j < Fpad, valid iff j < F.  Fpad is a multiple of 16
+    // when a readout runs (one W_out per 16-frame column tile) and a multiple of the tile when
+    // every group has its own weight set, so a tile never mixes weight sets.
     int n_frames;          // total sequences
-    int frames_per_pgroup; // parameter group (W_out, scalings, x0/y0) = frame / this
-    int frames_per_tgroup; // tiles never straddle a multiple of this
-    int tiles_per_tgroup;
+    int n_groups;
+    int F;                 // frames per group
+    int Fpad;              // slots per group
     int n_wsets;
     int T_in;              // valid input rows per frame
     int S;                 // recurrence steps
@@ -51,6 +55,14 @@ struct DetectParams {
     const double* p_i; const uint8_t* tx_bits;
     long long* err; long long* bits; double* X_hat;
 };
+
+// slot -> frame index (or -1 for padding) and its group
+__device__ __forceinline__ int slot_frame(const RecurParams& p, int slot, int& grp) {
+    grp = slot / p.Fpad;
+    const int j = slot - grp * p.Fpad;
+    const int fr = grp * p.F + j;
+    return (j < p.F && grp < p.n_groups && fr < p.n_frames) ? fr : -1;
+}
 
 inline __host__ __device__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

@@ -20,15 +20,18 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
     double* Yn = Fc + FB * n_out;            // [FB][n_out]  readout of this step
 
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int tile = blockIdx.x;
-    const int tg = tile / p.tiles_per_tgroup, ti = tile % p.tiles_per_tgroup;
-    const int frame0 = tg * p.frames_per_tgroup + ti * FB;
-    int valid = p.frames_per_tgroup - ti * FB;
-    if (valid > FB) valid = FB;
-    if (frame0 + valid > p.n_frames) valid = p.n_frames - frame0;
-    if (valid <= 0) return;
-    const int pg0 = frame0 / p.frames_per_pgroup;
-    const int wset = pg0 % p.n_wsets;
+    const int slot0 = blockIdx.x * FB;
+    // per-slot frame / group tables (LDS, FB entries)
+    __shared__ int s_fr[FB], s_grp[FB];
+    if (tid < FB) {
+        int grp;
+        s_fr[tid] = slot_frame(p, slot0 + tid, grp);
+        s_grp[tid] = grp;
+    }
+    __syncthreads();
+    int grp0 = slot0 / p.Fpad;
+    if (grp0 >= p.n_groups) return;
+    const int wset = grp0 % p.n_wsets;
     const double* Wk = reinterpret_cast<const double*>(
         reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride);
     const int ncols = n_res + n_in;
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
     for (int i = tid; i < FB * n_res; i += nth) {
         int f = i / n_res, r = i % n_res;
         double v = 0.0;
-        if (p.x0 && f < valid) v = p.x0[(size_t)((frame0 + f) / p.frames_per_pgroup) * n_res + r];
+        if (p.x0 && s_fr[f] >= 0) v = p.x0[(size_t)s_grp[f] * n_res + r];
         X0[i] = v;
     }
     auto stage_io = [&](int s) {
@@ -47,8 +50,9 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
         for (int i = tid; i < FB * n_in; i += nth) {
             int f = i / n_in, c = i % n_in;
             double v = 0.0;
-            if (f < valid) {
-                int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+            const int fr = s_fr[f];
+            if (fr >= 0) {
+                const int pg = s_grp[f];
                 double raw = (row < p.T_in) ? p.U[((size_t)fr * p.T_in + row) * n_in + c] : 0.0;
                 double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + c] : 1.0;
                 double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + c] : 0.0;
@@ -60,8 +64,9 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
             for (int i = tid; i < FB * n_out; i += nth) {
                 int f = i / n_out, c = i % n_out;
                 double v = 0.0;
-                if (f < valid) {
-                    int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+                const int fr = s_fr[f];
+                if (fr >= 0) {
+                    const int pg = s_grp[f];
                     double raw = p.D[((size_t)fr * (p.S + 1) + s) * n_out + c];
                     double sc = p.t_scale ? p.t_scale[(size_t)pg * n_out + c] : 1.0;
                     double sh = p.t_shift ? p.t_shift[(size_t)pg * n_out + c] : 0.0;
@@ -75,14 +80,16 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
         for (int i = tid; i < FB * n_out; i += nth) {
             int f = i / n_out, c = i % n_out;
             double v = 0.0;
-            if (p.y0 && f < valid) v = p.y0[(size_t)((frame0 + f) / p.frames_per_pgroup) * n_out + c];
+            if (p.y0 && s_fr[f] >= 0) v = p.y0[(size_t)s_grp[f] * n_out + c];
             Fc[i] = v;
         }
     } else {
         // E row 0 = [0, scale(u[0])]  (pyESN.py:179,189)
-        for (int i = tid; i < valid * ncols; i += nth) {
+        for (int i = tid; i < FB * ncols; i += nth) {
             int f = i / ncols, c = i % ncols;
-            int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+            const int fr = s_fr[f];
+            if (fr < 0) continue;
+            const int pg = s_grp[f];
             double v = 0.0;
             if (c >= n_res) {
                 int ci = c - n_res;
@@ -134,8 +141,8 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
             for (int f = 0; f < FB; ++f) {
                 double x0v = tanh(a0[f]);
                 double x1v = tanh(a1[f]);
-                if (p.noise_mode != ESN_NOISE_NONE && f < valid) {
-                    const uint32_t fr = frame0 + f;
+                if (p.noise_mode != ESN_NOISE_NONE && s_fr[f] >= 0) {
+                    const uint32_t fr = (uint32_t)s_fr[f];
                     double u0, u1 = 0.0;
                     if (p.noise_mode == ESN_NOISE_TENSOR) {
                         const double* nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
@@ -157,10 +164,11 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
 
         if (p.harvest) {
             // E row s+1 = [x_{s+1}, u_scaled[s+1]]
-            for (int i = tid; i < valid * ncols; i += nth) {
+            for (int i = tid; i < FB * ncols; i += nth) {
                 int f = i / ncols, c = i % ncols;
+                if (s_fr[f] < 0) continue;
                 double v = (c < n_res) ? Xn[f * n_res + c] : Uc[f * n_in + (c - n_res)];
-                p.E[((size_t)(frame0 + f) * (p.S + 1) + (s + 1)) * ncols + c] = v;
+                p.E[((size_t)s_fr[f] * (p.S + 1) + (s + 1)) * ncols + c] = v;
             }
         } else {
             // ---- y = W_out [x_{s+1}; u]  (one wave per (output, frame) pair) ---
@@ -168,8 +176,8 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
             for (int pr = wv; pr < FB * n_out; pr += nwv) {
                 int f = pr / n_out, o = pr % n_out;
                 double acc = 0.0;
-                if (f < valid) {
-                    int pg = (frame0 + f) / p.frames_per_pgroup;
+                if (s_fr[f] >= 0) {
+                    int pg = s_grp[f];
                     const double* wo = reinterpret_cast<const double*>(
                         reinterpret_cast<const char*>(p.packed_wout) + (size_t)pg * p.wout_stride)
                         + (size_t)o * ncols;
@@ -190,8 +198,8 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
                 int f = i / n_out, c = i % n_out;
                 double y = Yn[i];
                 Fc[i] = y;
-                if (f < valid && s >= p.transient) {
-                    int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+                if (s_fr[f] >= 0 && s >= p.transient) {
+                    int fr = s_fr[f], pg = s_grp[f];
                     double sc = p.t_scale ? p.t_scale[(size_t)pg * n_out + c] : 1.0;
                     double sh = p.t_shift ? p.t_shift[(size_t)pg * n_out + c] : 0.0;
                     p.Y[((size_t)fr * out_rows + (s - p.transient)) * n_out + c] = (y - sh) / sc;
@@ -210,7 +218,7 @@ size_t recur_f64_lds_bytes(int FB, int n_res, int n_in, int n_out) {
 
 int launch_recur_f64(const RecurParams& p, hipStream_t stream) {
     // frames per tile: 8 while the double-buffered state fits in 150 KB, else 4/2/1
-    int FB = p.g.Bt;
+    const int FB = p.g.Bt;
     size_t lds = recur_f64_lds_bytes(FB, p.n_res, p.n_in, p.n_out);
     int threads = round_up((p.n_res + 1) / 2, 64);
     if (threads > 1024) threads = 1024;

@@ -120,33 +120,43 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     const int nkg64 = g.Kp * ES / 64;        // 64-byte k-groups per row (readout)
 
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
-    const int tg = tile / p.tiles_per_tgroup, ti = tile % p.tiles_per_tgroup;
-    const int frame0 = tg * p.frames_per_tgroup + ti * BT;
-    int valid = p.frames_per_tgroup - ti * BT;
-    if (valid > BT) valid = BT;
-    if (frame0 + valid > p.n_frames) valid = p.n_frames - frame0;
-    if (valid <= 0) return;
-    const int pg0 = frame0 / p.frames_per_pgroup;
-    const int wset = pg0 % p.n_wsets;
+    const int slot0 = tile * BT;
+    const int grp0 = slot0 / p.Fpad;
+    if (grp0 >= p.n_groups) return;
+    const int wset = grp0 % p.n_wsets;
     const char* wp = reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride
                      + ((size_t)(wave * MT) * nkg * 64 + lane) * 16;
-    const char* wop = p.harvest ? nullptr
-        : reinterpret_cast<const char*>(p.packed_wout) + (size_t)pg0 * p.wout_stride + (size_t)lane * 16;
     const int n_ot = (n_out + 15) / 16;
-    // readout image trailer: {1/gain, gain} of this group's power-of-two W_out scaling
-    const float wo_inv = p.harvest ? 1.f : *reinterpret_cast<const float*>(
-        reinterpret_cast<const char*>(p.packed_wout) + (size_t)pg0 * p.wout_stride
-        + (size_t)TR::PARTS * n_ot * nkg64 * 1024);
     const int out_rows = p.S - p.transient;
     const int ncols = n_res + n_in;
     const float in_gain = 1.0f, fb_gain = 1.0f;   // reserved: power-of-two operand gains
 
-    // ---- LDS init: state rows, padding, first inputs, initial feedback ---------
+    // frame / group of the column this lane owns in each 32-wide column tile (GEMM layout)
+    int col_fr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { int gtmp; col_fr[nt] = slot_frame(p, slot0 + nt * 32 + r, gtmp); }
+    // column-owner view: wave c16 < BT/16 owns frames 16*c16 .. 16*c16+15 (one group: Fpad % 16 == 0)
+    int ro_grp = 0;
+    const int ro_fr = slot_frame(p, slot0 + (wave < BT / 16 ? wave : 0) * 16 + (lane & 15), ro_grp);
+    const char* wop = nullptr;
+    float wo_inv = 1.f;
+    if (!p.harvest && wave < BT / 16) {
+        const int cg = (slot0 + wave * 16) / p.Fpad;
+        if (cg < p.n_groups) {
+            const char* base = reinterpret_cast<const char*>(p.packed_wout) + (size_t)cg * p.wout_stride;
+            wop = base + (size_t)lane * 16;
+            // readout image trailer: {1/gain, gain} of this group's power-of-two W_out scaling
+            wo_inv = *reinterpret_cast<const float*>(base + (size_t)TR::PARTS * n_ot * nkg64 * 1024);
+        }
+    }
+
+    // ---- LDS init: state rows, padding, initial feedback -----------------------
     for (int i = tid; i < BT * g.Ks; i += NTHREADS) {
         int f = i / g.Ks, k = i % g.Ks;
         float v = 0.f;
-        if (f < valid) {
-            int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+        int pg;
+        const int fr = slot_frame(p, slot0 + f, pg);
+        if (fr >= 0) {
             if (k < n_res) {
                 if (p.x0) v = (float)p.x0[(size_t)pg * n_res + k];
             } else if (k >= g.kfb && k < g.kfb + n_out && !p.harvest) {
@@ -157,9 +167,11 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     }
     if (p.harvest) {
         // E row 0 = [0, scale(u[0])]  (pyESN.py:179,189)
-        for (int i = tid; i < valid * ncols; i += NTHREADS) {
+        for (int i = tid; i < BT * ncols; i += NTHREADS) {
             int f = i / ncols, c = i % ncols;
-            int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+            int pg;
+            const int fr = slot_frame(p, slot0 + f, pg);
+            if (fr < 0) continue;
             double v = 0.0;
             if (c >= n_res) {
                 int ci = c - n_res;
@@ -180,8 +192,9 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         for (int i = lane; i < 16 * kin_p; i += 64) {
             int f = c16 * 16 + i / kin_p, c = i % kin_p;
             float v = 0.f;
-            if (f < valid && c < n_in) {
-                int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+            int pg;
+            const int fr = slot_frame(p, slot0 + f, pg);
+            if (fr >= 0 && c < n_in) {
                 double raw = (row < p.T_in) ? p.U[((size_t)fr * p.T_in + row) * n_in + c] : 0.0;
                 double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + c] : 1.0;
                 double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + c] : 0.0;
@@ -194,8 +207,9 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             for (int i = lane; i < 16 * kfb_p; i += 64) {
                 int f = c16 * 16 + i / kfb_p, c = i % kfb_p;
                 float v = 0.f;
-                if (f < valid && c < n_out) {
-                    int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+                int pg;
+                const int fr = slot_frame(p, slot0 + f, pg);
+                if (fr >= 0 && c < n_out) {
                     double raw = p.D[((size_t)fr * (p.S + 1) + s) * n_out + c];
                     double sc = p.t_scale ? p.t_scale[(size_t)pg * n_out + c] : 1.0;
                     double sh = p.t_shift ? p.t_shift[(size_t)pg * n_out + c] : 0.0;
@@ -247,11 +261,11 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = nt * 32 + r;
-            const uint32_t fr = frame0 + col;
+            const int fr = col_fr[nt];
             uint32_t key = 0;
             const double* nz = nullptr;
-            if (p.noise_mode == ESN_NOISE_COUNTER) key = noise_key(p.seed, fr, (uint32_t)s);
-            if (p.noise_mode == ESN_NOISE_TENSOR && col < valid)
+            if (p.noise_mode == ESN_NOISE_COUNTER) key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s);
+            if (p.noise_mode == ESN_NOISE_TENSOR && fr >= 0)
                 nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -277,15 +291,18 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 
         if (p.harvest) {
             // E row s+1 = [x_{s+1}, u_scaled[s+1]] straight from the LDS image
-            for (int i = tid; i < valid * ncols; i += NTHREADS) {
+            for (int i = tid; i < BT * ncols; i += NTHREADS) {
                 int f = i / ncols, c = i % ncols;
+                int pg;
+                const int fr = slot_frame(p, slot0 + f, pg);
+                if (fr < 0) continue;
                 int k = (c < n_res) ? c : g.kin + (c - n_res);
                 float v = TR::load1(zt + (size_t)f * row_bytes + (size_t)k * ES);
-                p.E[((size_t)(frame0 + f) * (p.S + 1) + (s + 1)) * ncols + c] = (double)v;
+                p.E[((size_t)fr * (p.S + 1) + (s + 1)) * ncols + c] = (double)v;
             }
             __syncthreads();
             if (wave < BT / 16 && s + 1 < p.S) stage_io(s + 1, wave);
-        } else if (wave < BT / 16) {
+        } else if (wave < BT / 16 && wop) {
             // ================= phase R: readout + feedback + next inputs ==========
             const int c16 = wave;
             const int q = lane >> 4, fc = lane & 15;
@@ -308,8 +325,8 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                 if (o0 < round_up(n_out, 4)) {
                     TR::store4(zt + (size_t)f * row_bytes + (size_t)(g.kfb + o0) * ES,
                                y[0] * fb_gain, y[1] * fb_gain, y[2] * fb_gain, y[3] * fb_gain);
-                    if (s >= p.transient && f < valid) {
-                        const int fr = frame0 + f, pg = fr / p.frames_per_pgroup;
+                    if (s >= p.transient && ro_fr >= 0) {
+                        const int fr = ro_fr, pg = ro_grp;
                         double* yo = p.Y + ((size_t)fr * out_rows + (s - p.transient)) * n_out;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {

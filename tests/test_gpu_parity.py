@@ -192,7 +192,8 @@ def test_per_group_reservoirs(amd):
     ws = [eo.draw_weights(np.random.RandomState(100 + g), n_in, n_out, n_res, 0.9, 0.2) for g in range(G)]
     bank = batched.ReservoirBank(n_in, n_out, n_res, np.stack([w[0] for w in ws]), np.stack([w[1] for w in ws]),
                                  np.stack([w[2] for w in ws]), noise=0.0)
-    u, d = rs.randn(G, t, n_in), rs.randn(G, t, n_out)
+    u = rs.randn(G, t, n_in)
+    d = np.tanh(u @ rs.randn(n_in, n_out)) + 0.3 * np.roll(u[:, :, :n_out], 1, axis=1)   # learnable teacher
     bank.fit(u, d, transient=4, precision="f64", noise_mode="none")
     assert int(bank.fit_status.sum().item()) == 0
     u2 = rs.randn(G * F, t, n_in)
@@ -207,9 +208,9 @@ def test_per_group_reservoirs(amd):
         for f in range(F):
             want = o.predict(u2[g * F + f], 2, continuation=False)
             assert rel_err(got[g * F + f], want) < 1e-9
-            # the teacher here is white noise, so the min-norm W_out is large and amplifies the
-            # float32 state round-off (cancellation in the readout): loose bound on purpose
-            assert rel_err(got32[g * F + f], want) < 2e-2
+            # 36 equations / 52 unknowns: the min-norm W_out amplifies float32 state round-off
+            # (cancellation in the readout), hence the looser float32 bound
+            assert rel_err(got32[g * F + f], want) < 5e-3
 
 
 @pytest.mark.parametrize("rows,cols", [(128, 528), (40, 40), (512, 104), (300, 90)])
