@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=4)
     ap.add_argument("--predict-only", action="store_true", help="time the predict+detect leg only")
+    ap.add_argument("--solve", default="auto", choices=["auto", "qr", "chol"])
     args = ap.parse_args()
 
     import numpy as np
@@ -116,7 +117,7 @@ def main():
     G = args.blocks or max(1, (5 * 256 * 128) // fpad)
     sweep = DetectorSweep(params, n_reservoir=args.n_res, noise=0.001, seed=1234 + rank,
                           precision=args.precision, fit_precision=args.fit_precision,
-                          reservoirs="shared", rank=rank, world_size=world)
+                          reservoirs="shared", rank=rank, world_size=world, solve_method=args.solve)
     data = sweep.src.blocks_fast(args.ebno, 0, rank * G, G, F)
     sweep.set_snr(args.ebno, G)
     err = torch.zeros(G, dtype=torch.int64, device=sweep.device)
@@ -184,10 +185,11 @@ def main():
             "config": {"workload": "configs[3]: OFDM 4x8 MIMO, TDL-B taps, 16-QAM, N=128, CP=7, d=3, N_res=%d, "
                                    "Eb/No %g dB, uncoded" % (args.n_res, args.ebno),
                        "blocks_per_rank": G, "frames_per_block": F, "frames_per_step": world * frames_per_step,
-                       "reservoir": "shared", "state_noise": 0.001, "fit": "harvest %s + QR f64" % args.fit_precision,
+                       "reservoir": "shared", "state_noise": 0.001, "fit": "harvest %s + %s f64 solve" % (args.fit_precision, args.solve),
                        "timed": "predict+detect" if args.predict_only else "train+predict+detect",
                        "parallelism": "blocks sharded over %d rank(s), one all_reduce of counters" % world},
             "ber": float(c[0]) / max(float(c[1]), 1.0),
+            "fit_groups_flagged": int(sweep.bank.fit_status.sum().item()),
             "predict_kernel_ms": kernel_ms,
             "predict_only_symbols_per_s": world * frames_per_step / (kernel_ms * 1e-3),
             "roofline": {"bound": "mfma", "kernel": "esn::recur_mfma_kernel (predict)", "achieved": achieved,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "esn_readout_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "esn_readout_solve_batch": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           _dp, _dp, _dp, _ip, _vp, _vp]),
+    "esn_readout_solve_chol_batch": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               _dp, _dp, _dp, _ip, _vp]),
     "esn_detect_count": (C.c_int, [_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _vp,
                                    _vp, _vp, _dp, _vp]),
 }

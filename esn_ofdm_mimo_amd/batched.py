@@ -131,13 +131,33 @@ class ReservoirBank:
                 _lib.stream_handle()), "esn_harvest_batch")
         return E
 
-    def solve(self, E, D, transient):
-        """W_out[g] = (pinv(E[g][transient:]) @ scale(D[g][transient:])).T ; returns (W_out, status)."""
+    def solve(self, E, D, transient, method="qr"):
+        """W_out[g] = (pinv(E[g][transient:]) @ scale(D[g][transient:])).T ; returns (W_out, status).
+
+        method "qr": float64 Householder QR (accurate to cond(E) eps; the drop-in's choice).
+        method "chol": float64 normal equations, Gram + Cholesky in LDS (min(rows, cols) <= 128,
+        n_out <= 8), an order of magnitude faster; groups whose pivot test fails are re-solved
+        with QR on the GPU.  "auto" = "chol" when the shape fits."""
         torch = self.torch
         E = _as_dev(E, torch, self.device)
         D = _as_dev(D, torch, self.device)
         g, t, cols = E.shape
         rows = t - transient
+        fits = min(rows, cols) <= 128 and self.n_outputs <= 8
+        if method == "auto":
+            method = "chol" if fits else "qr"
+        if method == "chol":
+            if not fits:
+                raise ValueError("method='chol' needs min(rows, cols) <= 128 and n_outputs <= 8")
+            with torch.cuda.device(self.device):
+                W_out = torch.empty((g, self.n_outputs, cols), dtype=torch.float64, device=self.device)
+                status = torch.empty(g, dtype=torch.int32, device=self.device)
+                check(self.lib.esn_readout_solve_chol_batch(
+                    ptr(E), ptr(D), g, t, int(transient), cols, self.n_outputs, ptr(self.t_scale),
+                    ptr(self.t_shift), ptr(W_out), ptr(status), _lib.stream_handle()),
+                    "esn_readout_solve_chol_batch")
+            self.last_solve_status = status        # checked lazily: no host sync on the fast path
+            return W_out, status
         with torch.cuda.device(self.device):
             wbytes = self.lib.esn_readout_solve_workspace_bytes(g, rows, cols, self.n_outputs)
             work = torch.empty(wbytes, dtype=torch.uint8, device=self.device)
@@ -149,9 +169,28 @@ class ReservoirBank:
                   "esn_readout_solve_batch")
         return W_out, status
 
-    def fit(self, U, D, transient=0, precision="f64", noise_mode="counter", noise_u=None, seed=0):
+    def resolve_failed(self, E, D, transient, W_out, status):
+        """Re-solve with QR (on the GPU) the groups a "chol" solve flagged; returns their count."""
+        torch = self.torch
+        bad = torch.nonzero(status).flatten()
+        nbad = int(bad.numel())
+        if nbad:
+            keep = (self.t_scale, self.t_shift)
+            self.t_scale = None if keep[0] is None else keep[0][bad].contiguous()
+            self.t_shift = None if keep[1] is None else keep[1][bad].contiguous()
+            try:
+                w2, st2 = self.solve(E[bad].contiguous(), _as_dev(D, torch, self.device)[bad].contiguous(),
+                                     transient, method="qr")
+            finally:
+                self.t_scale, self.t_shift = keep
+            W_out[bad] = w2
+            status[bad] = st2
+        return nbad
+
+    def fit(self, U, D, transient=0, precision="f64", noise_mode="counter", noise_u=None, seed=0,
+            method="qr"):
         E = self.harvest(U, D, precision, noise_mode, noise_u, seed)
-        W_out, status = self.solve(E, D, transient)
+        W_out, status = self.solve(E, D, transient, method=method)
         self.set_readout(W_out)
         self.fit_status = status
         return E

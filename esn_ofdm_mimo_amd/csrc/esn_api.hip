@@ -25,6 +25,9 @@ size_t solve_work_doubles(int rows, int cols, int n_out);
 int launch_readout_solve(const double* E, const double* D, int n_groups, int T, int transient,
                          int cols, int n_out, const double* t_scale, const double* t_shift,
                          double* W_out, int* status, void* workspace, hipStream_t stream);
+int launch_readout_chol(const double* E, const double* D, int n_groups, int T, int transient,
+                        int cols, int n_out, const double* t_scale, const double* t_shift,
+                        double* W_out, int* status, hipStream_t stream);
 // esn_detect.hip
 int launch_detect_count(const DetectParams& dp, hipStream_t stream);
 }  // namespace esn
@@ -215,6 +218,17 @@ int esn_readout_solve_batch(const double* E, const double* D, int n_groups, int 
     return hip_fail(launch_readout_solve(E, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
                                          status, workspace, (hipStream_t)stream),
                     "esn_readout_solve_batch");
+}
+
+int esn_readout_solve_chol_batch(const double* E, const double* D, int n_groups, int T, int transient, int cols,
+                                 int n_out, const double* t_scale, const double* t_shift, double* W_out,
+                                 int* status, void* stream) {
+    if (!E || !D || !W_out || !status) return fail(-1, "esn_readout_solve_chol_batch: null pointer");
+    if (n_groups <= 0 || T <= 0 || transient < 0 || transient >= T || cols <= 0 || n_out <= 0)
+        return fail(-1, "esn_readout_solve_chol_batch: invalid sizes");
+    return hip_fail(launch_readout_chol(E, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
+                                        status, (hipStream_t)stream),
+                    "esn_readout_solve_chol_batch");
 }
 
 int esn_detect_count(const double* Y, int n_frames, int frames_per_group, int n_sub, int n_t, int bits_per_sym,

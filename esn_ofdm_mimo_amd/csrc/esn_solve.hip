@@ -203,3 +203,195 @@ int launch_readout_solve(const double* E, const double* D, int n_groups, int T, 
 }
 
 }  // namespace esn
+
+// ---------------------------------------------------------------------------------
+// Fast path for well-conditioned batched fits: normal equations in float64 with the
+// Gram matrix (<= 128 x 128) and its Cholesky factor resident in LDS.
+//   rows <  cols:  G = A A^T,  G alpha = B,      W_out^T = A^T alpha   (minimum norm)
+//   rows >= cols:  G = A^T A,  G W_out^T = A^T B
+// Error ~ cond(A)^2 eps: with the model's state noise cond(A) ~ 1e3, i.e.
+// ~1e-10 -- far below the float32 harvest.  A non-positive / tiny pivot sets status=1 and
+// the caller re-solves that group with the QR kernel.
+// ---------------------------------------------------------------------------------
+namespace esn {
+
+constexpr int CH_NP = 128;        // padded Gram dimension
+constexpr int CH_LD = CH_NP + 1;  // LDS row stride (doubles): conflict-free row-strided reads
+constexpr int CH_KC = 32;         // k-chunk staged per pass
+
+__global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
+    extern __shared__ __attribute__((aligned(16))) char chol_smem[];
+    double* Gs = reinterpret_cast<double*>(chol_smem);            // [CH_NP][CH_LD]   (phase 2+)
+    double* As = Gs;                                               // [CH_KC][CH_NP+4] (phase 1, aliased)
+    double* Bs = Gs + CH_NP * CH_LD;                               // [nrhs][CH_NP] rhs / solution
+    __shared__ double sh_d[2];
+    __shared__ int sh_bad;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int rows = sp.T - sp.transient, cols = sp.cols, nrhs = sp.n_out;
+    const bool wide = rows < cols;
+    const int n = wide ? rows : cols;      // Gram dimension (<= CH_NP)
+    const int m = wide ? cols : rows;      // contraction length
+    const double* A = sp.E + ((size_t)g * sp.T + sp.transient) * cols;   // [rows][cols]
+    const double* Dg = sp.D + ((size_t)g * sp.T + sp.transient) * nrhs;
+    constexpr int AS_LD = CH_NP + 4;
+
+    // ---- phase 1: G = sum_k a_k a_k^T, 4x4 register tile per thread ----------------
+    const int tx = tid & 31, ty = tid >> 5;          // G rows 4*ty.., cols 4*tx..
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    // tall case also needs A^T B: thread (o, i) partial sums, o < nrhs, i < n  -> first nrhs*128 threads
+    double atb = 0.0;
+    const int ao = tid / CH_NP, ai = tid % CH_NP;
+    for (int k0 = 0; k0 < m; k0 += CH_KC) {
+        __syncthreads();
+        // stage As[kk][i] = a(i, k0+kk);  wide: A[i][k], tall: A[k][i]
+        for (int e = tid; e < CH_KC * CH_NP; e += 1024) {
+            int kk, i;
+            if (wide) { i = e / CH_KC; kk = e % CH_KC; } else { kk = e / CH_NP; i = e % CH_NP; }
+            const int k = k0 + kk;
+            double v = 0.0;
+            if (i < n && k < m) v = wide ? A[(size_t)i * cols + k] : A[(size_t)k * cols + i];
+            As[kk * AS_LD + i] = v;
+        }
+        __syncthreads();
+        const int kmax = (m - k0 < CH_KC) ? m - k0 : CH_KC;
+        for (int kk = 0; kk < kmax; ++kk) {
+            const double* row = As + kk * AS_LD;
+            double a0 = row[4 * ty], a1 = row[4 * ty + 1], a2 = row[4 * ty + 2], a3 = row[4 * ty + 3];
+            double b0 = row[4 * tx], b1 = row[4 * tx + 1], b2 = row[4 * tx + 2], b3 = row[4 * tx + 3];
+            acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
+            acc[0][2] = fma(a0, b2, acc[0][2]); acc[0][3] = fma(a0, b3, acc[0][3]);
+            acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
+            acc[1][2] = fma(a1, b2, acc[1][2]); acc[1][3] = fma(a1, b3, acc[1][3]);
+            acc[2][0] = fma(a2, b0, acc[2][0]); acc[2][1] = fma(a2, b1, acc[2][1]);
+            acc[2][2] = fma(a2, b2, acc[2][2]); acc[2][3] = fma(a2, b3, acc[2][3]);
+            acc[3][0] = fma(a3, b0, acc[3][0]); acc[3][1] = fma(a3, b1, acc[3][1]);
+            acc[3][2] = fma(a3, b2, acc[3][2]); acc[3][3] = fma(a3, b3, acc[3][3]);
+        }
+        if (!wide && ao < nrhs) {
+            const double sc = sp.t_scale ? sp.t_scale[(size_t)g * nrhs + ao] : 1.0;
+            const double sh = sp.t_shift ? sp.t_shift[(size_t)g * nrhs + ao] : 0.0;
+            for (int kk = 0; kk < kmax; ++kk)
+                atb = fma(As[kk * AS_LD + ai], Dg[(size_t)(k0 + kk) * nrhs + ao] * sc + sh, atb);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: G and the right-hand sides into LDS ----------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Gs[(4 * ty + i) * CH_LD + 4 * tx + j] = acc[i][j];
+    if (tid == 0) sh_bad = 0;
+    for (int e = tid; e < nrhs * CH_NP; e += 1024) {
+        const int o = e / CH_NP, i = e % CH_NP;
+        double v = 0.0;
+        if (wide && i < n) {
+            const double sc = sp.t_scale ? sp.t_scale[(size_t)g * nrhs + o] : 1.0;
+            const double sh = sp.t_shift ? sp.t_shift[(size_t)g * nrhs + o] : 0.0;
+            v = Dg[(size_t)i * nrhs + o] * sc + sh;
+        }
+        if (wide) Bs[e] = v;
+    }
+    __syncthreads();
+    if (!wide && ao < nrhs) Bs[ao * CH_NP + ai] = (ai < n) ? atb : 0.0;
+    // largest diagonal entry (pivot tolerance)
+    double dmax = 0.0;
+    if (tid < n) dmax = Gs[tid * CH_LD + tid];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_down(dmax, off));
+    __shared__ double sh_max[2];
+    if (tid < 128 && lane == 0) sh_max[wv] = dmax;
+    __syncthreads();
+    const double piv_tol = fmax(sh_max[0], sh_max[1]) * 1e-14;
+
+    // ---- phase 3: left-looking Cholesky, 8 threads per row, one column per iteration ----
+    const int ri = tid >> 3, part = tid & 7;         // row 0..127
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0;
+        if (ri >= j && ri < n) {
+            const double* Li = Gs + ri * CH_LD;
+            const double* Lj = Gs + j * CH_LD;
+            for (int k = part; k < j; k += 8) s = fma(Li[k], Lj[k], s);
+        }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        double v = 0.0;
+        if (ri >= j && ri < n) v = Gs[ri * CH_LD + j] - s;
+        if (ri == j && part == 0) {
+            if (!(v > piv_tol)) { sh_bad = 1; v = 1.0; sh_d[0] = 0.0; } else { sh_d[0] = 1.0; }
+            sh_d[1] = sqrt(v);
+        }
+        __syncthreads();
+        const double d = sh_d[1];
+        if (ri >= j && ri < n && part == 0) {
+            // a rejected pivot zeroes its column (the direction is dropped, as pinv would)
+            Gs[ri * CH_LD + j] = (ri == j) ? d : (sh_d[0] != 0.0 ? v / d : 0.0);
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 4: L L^T x = b, one wave per right-hand side ------------------------------
+    for (int o = wv; o < nrhs; o += 16) {
+        double* x = Bs + o * CH_NP;
+        for (int j = 0; j < n; ++j) {
+            const double* Lj = Gs + j * CH_LD;
+            double a = 0.0;
+            for (int k = lane; k < j; k += 64) a = fma(Lj[k], x[k], a);
+            a = wave_sum(a);
+            if (lane == 0) x[j] = (x[j] - a) / Lj[j];
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int j = n - 1; j >= 0; --j) {
+            double a = 0.0;
+            for (int k = j + 1 + lane; k < n; k += 64) a = fma(Gs[k * CH_LD + j], x[k], a);
+            a = wave_sum(a);
+            if (lane == 0) x[j] = (x[j] - a) / Gs[j * CH_LD + j];
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 5: W_out ---------------------------------------------------------------------
+    if (wide) {
+        // W_out[o][c] = sum_i A[i][c] alpha[i][o]
+        for (int e = tid; e < nrhs * cols; e += 1024) {
+            const int o = e / cols, c = e % cols;
+            const double* al = Bs + o * CH_NP;
+            double a = 0.0;
+            for (int i = 0; i < n; ++i) a = fma(A[(size_t)i * cols + c], al[i], a);
+            sp.W_out[((size_t)g * nrhs + o) * cols + c] = a;
+        }
+    } else {
+        for (int e = tid; e < nrhs * cols; e += 1024) {
+            const int o = e / cols, c = e % cols;
+            sp.W_out[((size_t)g * nrhs + o) * cols + c] = Bs[o * CH_NP + c];
+        }
+    }
+    if (tid == 0) sp.status[g] = sh_bad;
+}
+
+int launch_readout_chol(const double* E, const double* D, int n_groups, int T, int transient,
+                        int cols, int n_out, const double* t_scale, const double* t_shift,
+                        double* W_out, int* status, hipStream_t stream) {
+    SolveParams sp;
+    const int rows = T - transient;
+    const int n = rows < cols ? rows : cols;
+    if (n > CH_NP || n_out > 8) return -1;     // tall case stages A^T B with nrhs*128 <= 1024 threads
+    sp.E = E; sp.D = D; sp.n_groups = n_groups; sp.T = T; sp.transient = transient;
+    sp.cols = cols; sp.n_out = n_out; sp.t_scale = t_scale; sp.t_shift = t_shift;
+    sp.W_out = W_out; sp.status = status; sp.work = nullptr; sp.work_stride = 0;
+    sp.wide = rows < cols; sp.m = sp.wide ? cols : rows; sp.n = n;
+    const size_t lds = sizeof(double) * ((size_t)CH_NP * CH_LD + (size_t)n_out * CH_NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(readout_chol_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(readout_chol_kernel, dim3(n_groups), dim3(1024), lds, stream, sp);
+    return (int)hipGetLastError();
+}
+
+}  // namespace esn

@@ -241,11 +241,12 @@ class DetectorSweep:
 
     def __init__(self, params: LinkParams, n_reservoir=512, spectral_radius=0.9, sparsity=0.1, noise=0.001,
                  seed=0, precision="f32", fit_precision="f64", reservoirs="shared", pool=8, device=None,
-                 rank=0, world_size=1):
+                 rank=0, world_size=1, solve_method="auto"):
         torch = _lib.require_gpu()
         self.torch, self.p = torch, params
         self.rank, self.world = rank, world_size
         self.precision, self.fit_precision = precision, fit_precision
+        self.solve_method = solve_method
         self.n_in, self.n_out, self.n_res = 2 * params.n_r, 2 * params.n_t, n_reservoir
         self.seed = seed
         self.src = FrameSource(params, device, seed)
@@ -274,7 +275,18 @@ class DetectorSweep:
         D = torch.zeros((g, t + d, self.n_out), dtype=torch.float64, device=self.device)
         U[:, :t] = _view_real(pilot_y)
         D[:, d:d + t] = _view_real(pilot_x)
-        self.bank.fit(U, D, transient=d + p.cp, precision=self.fit_precision, noise_mode="counter", seed=seed)
+        self._fit_io = (U, D, d + p.cp)
+        return self.bank.fit(U, D, transient=d + p.cp, precision=self.fit_precision, noise_mode="counter",
+                             seed=seed, method=self.solve_method)
+
+    def repair_fit(self, E):
+        """Host-synchronising check of the last fit: groups the Cholesky path flagged are re-solved
+        with the QR kernel (GPU).  Returns how many were."""
+        U, D, tr = self._fit_io
+        n = self.bank.resolve_failed(E, D, tr, self.bank.W_out, self.bank.fit_status)
+        if n:
+            self.bank.set_readout(self.bank.W_out)
+        return n
 
     def detect(self, data_y, data_bits, frames_per_block, err, bits, seed=0, out=None):
         """driver:433-456 for all data frames of G blocks: predict (d trailing zero rows synthesised
@@ -299,7 +311,8 @@ class DetectorSweep:
                 g = len(ids)
                 data = self.src.blocks(ebno, si, ids, F)
                 self.set_snr(ebno, g)
-                self.train(data["pilot_y"], data["pilot_x"], seed=self.seed + 1000 * si + ids[0])
+                E = self.train(data["pilot_y"], data["pilot_x"], seed=self.seed + 1000 * si + ids[0])
+                self.repair_fit(E)
                 err = torch.zeros(g, dtype=torch.int64, device=self.device)
                 nb = torch.zeros(g, dtype=torch.int64, device=self.device)
                 self.detect(data["data_y"], data["data_bits"], F, err, nb, seed=self.seed + 1000 * si + ids[0])

@@ -27,7 +27,8 @@
  *                           (:146-152); batched over B frames in G groups.
  *   esn_harvest_batch       state-harvest loop of ESN.fit (:176-182,189) ->
  *                           extended states [states, inputs_scaled].
- *   esn_readout_solve_batch pinv solve of ESN.fit (:191-192).
+ *   esn_readout_solve_batch, esn_readout_solve_chol_batch
+ *                           pinv solve of ESN.fit (:191-192).
  *   esn_detect_count        driver tail: reconstruct (:47-58 of the 4x8 driver),
  *                           (1/N) FFT / sqrt(Pi) (:439-441), hard decision
  *                           (:95-103), bit-error count (:451-456).
@@ -147,6 +148,16 @@ int esn_readout_solve_batch(const double* E, const double* D, int n_groups, int 
                             int transient, int cols, int n_out,
                             const double* t_scale, const double* t_shift,
                             double* W_out, int* status, void* workspace, void* stream);
+
+/* Same contract, normal equations in float64 with the Gram matrix (min(rows, cols) <= 128) and its
+ * Cholesky factor resident in LDS -- the fast path for well-conditioned batched fits (with the
+ * model's state noise cond(E) ~ 1e3, error ~ cond^2 eps ~ 1e-10).  status[g] = 1 when a pivot was
+ * rejected: re-solve that group with esn_readout_solve_batch.  Needs n_out <= 8; returns -2 when
+ * the shape does not fit.  No workspace. */
+int esn_readout_solve_chol_batch(const double* E, const double* D, int n_groups, int T,
+                                 int transient, int cols, int n_out,
+                                 const double* t_scale, const double* t_shift,
+                                 double* W_out, int* status, void* stream);
 
 /* Fused detector tail: Y [B][N][2 N_t] time-domain ESN outputs
  * -> (1/N) FFT_N / sqrt(Pi[group]) -> nearest unit-power square-QAM point ->

@@ -213,8 +213,9 @@ def test_per_group_reservoirs(amd):
             assert rel_err(got32[g * F + f], want) < 5e-3
 
 
+@pytest.mark.parametrize("method,tol", [("qr", 1e-9), ("chol", 1e-7)])
 @pytest.mark.parametrize("rows,cols", [(128, 528), (40, 40), (512, 104), (300, 90)])
-def test_readout_solve_vs_pinv(amd, rows, cols):
+def test_readout_solve_vs_pinv(amd, rows, cols, method, tol):
     _, _, batched = amd
     rs = np.random.RandomState(rows + cols)
     G, n_out, tr = 3, 4, 5
@@ -224,11 +225,34 @@ def test_readout_solve_vs_pinv(amd, rows, cols):
     D = rs.randn(G, rows + tr, n_out)
     t_scale = rs.rand(G, n_out) + 0.5
     bank.set_scaling(None, None, t_scale, None)
-    W, status = bank.solve(E, D, tr)
+    W, status = bank.solve(E, D, tr, method=method)
     assert int(status.sum().item()) == 0
     for g in range(G):
         want = (np.linalg.pinv(E[g, tr:]) @ (D[g, tr:] * t_scale[g])).T
-        assert rel_err(W[g].cpu().numpy(), want) < 1e-9
+        assert rel_err(W[g].cpu().numpy(), want) < tol
+
+
+def test_chol_flags_rank_deficiency_and_qr_repairs(amd):
+    """A duplicated row makes the Gram singular: the Cholesky path must say so (status 1), and the
+    QR re-solve of the flagged group must match pinv's minimum-norm answer on the consistent part."""
+    _, _, batched = amd
+    rs = np.random.RandomState(8)
+    G, rows, cols, n_out = 3, 20, 50, 2
+    bank = batched.ReservoirBank(cols - 2, n_out, 2, np.zeros((2, 2)), np.zeros((2, cols - 2)), np.zeros((2, n_out)))
+    E = rs.randn(G, rows, cols)
+    D = rs.randn(G, rows, n_out)
+    E[1, 7] = E[1, 3]
+    D[1, 7] = D[1, 3]                       # consistent duplicate: pinv solution exists and is finite
+    W, status = bank.solve(E, D, 0, method="chol")
+    st = status.cpu().numpy()
+    assert st[0] == 0 and st[2] == 0 and st[1] == 1
+    import torch
+    n = bank.resolve_failed(torch.as_tensor(E, device=W.device), D, 0, W, status)
+    assert n == 1
+    for g in (0, 2):
+        assert rel_err(W[g].cpu().numpy(), (np.linalg.pinv(E[g]) @ D[g]).T) < 1e-7
+    # flagged group after QR: reproduces the teacher on every row (the duplicate included)
+    assert rel_err(E[1] @ W[1].cpu().numpy().T, D[1]) < 1e-6
 
 
 def test_detect_count_vs_oracle(amd, golden):
