@@ -7,7 +7,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libesn_hip.so")
-SOURCES = ["esn_api.hip", "esn_pack.hip", "esn_recur_f64.hip", "esn_recur_mfma.hip",
+SOURCES = ["esn_api.hip", "esn_pack.hip", "esn_recur_f64.hip", "esn_recur_mfma.hip", "esn_recur_mfma_f32.hip", "esn_recur_mfma_f16.hip",
+           "esn_recur_mfma_bf16.hip",
            "esn_solve.hip", "esn_detect.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
@@ -22,17 +23,26 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
+def build_library(force=False, verbose=True, stamps=False):
+    """stamps=True builds the diagnostic variant libesn_hip_stamps.so (-DESN_STAMPS: in-kernel
+    s_memtime phase stamps; never used for timing or by the product)."""
+    global LIB
+    if stamps:
+        return _build(os.path.join(PKG, "libesn_hip_stamps.so"), "build_stamps", ["-DESN_STAMPS"], verbose)
     if not force and not _stale():
         return LIB
+    return _build(LIB, "build", [], verbose)
+
+
+def _build(LIB, bdir, extra, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    os.makedirs(os.path.join(PKG, bdir), exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(PKG, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(PKG, bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, pr in procs:
         out, _ = pr.communicate()
@@ -47,4 +57,4 @@ def build_library(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    print(build_library(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

@@ -11,7 +11,7 @@ namespace esn {
 int launch_recur_f64(const RecurParams& p, hipStream_t stream);
 size_t recur_f64_lds_bytes(int FB, int n_res, int n_in, int n_out);
 // esn_recur_mfma.hip
-bool mfma_geometry(int precision, int n_res, int n_in, int n_out, Geometry* g);
+bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
 // esn_pack.hip
 size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
@@ -55,7 +55,7 @@ static bool check_shape(const esn_shape_t* s) {
 }
 
 // Geometry for a precision; for ESN_F64 only Bt (frames per tile) is meaningful.
-static bool geometry_for(int precision, const esn_shape_t* s, Geometry* g) {
+static bool geometry_for(int precision, const esn_shape_t* s, Geometry* g, bool harvest = false) {
     memset(g, 0, sizeof(*g));
     if (precision == ESN_F64) {
         int fb = 8;
@@ -65,8 +65,16 @@ static bool geometry_for(int precision, const esn_shape_t* s, Geometry* g) {
         return true;
     }
     if (precision < ESN_F64 || precision > ESN_BF16) return false;
-    return mfma_geometry(precision, s->n_res, s->n_in, s->n_out, g);
+    return mfma_geometry(precision, s->n_res, s->n_in, s->n_out, harvest, g);
 }
+
+#ifdef ESN_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" void esn_debug_set_stamp_buffer(void* dev) { g_stamp_buf = (unsigned long long*)dev; }
+#define ESN_SET_STAMPS(p) (p).stamps = g_stamp_buf
+#else
+#define ESN_SET_STAMPS(p) (p).stamps = nullptr
+#endif
 
 extern "C" {
 
@@ -130,10 +138,11 @@ int esn_pack_readout(int precision, const esn_shape_t* shape, int n_groups, cons
                     "esn_pack_readout");
 }
 
-static int fill_common(RecurParams& p, int precision, const esn_shape_t* shape, const char* who) {
+static int fill_common(RecurParams& p, int precision, const esn_shape_t* shape, const char* who,
+                       bool harvest = false) {
     memset(&p, 0, sizeof(p));
     if (!check_shape(shape)) return fail(-1, "%s: invalid shape", who);
-    if (!geometry_for(precision, shape, &p.g)) return fail(-2, "%s: unsupported shape/precision", who);
+    if (!geometry_for(precision, shape, &p.g, harvest)) return fail(-2, "%s: unsupported shape/precision", who);
     p.n_res = shape->n_res; p.n_in = shape->n_in; p.n_out = shape->n_out;
     p.teacher_forcing = shape->teacher_forcing ? 1 : 0;
     p.n_wsets = shape->n_wsets;
@@ -170,6 +179,7 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     p.U = U; p.x0 = x0; p.y0 = y0; p.noise_u = noise_u;
     p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
     p.Y = Y;
+    ESN_SET_STAMPS(p);
     int e = (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
                                    : launch_recur_mfma(precision, p, (hipStream_t)stream);
     return hip_fail(e, "esn_predict_batch");
@@ -180,10 +190,8 @@ int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packe
                       const double* D, int n_groups, int T, double noise, int noise_mode, const double* noise_u,
                       uint64_t seed, double* E, void* stream) {
     RecurParams p;
-    int rc = fill_common(p, precision, shape, "esn_harvest_batch");
+    int rc = fill_common(p, precision, shape, "esn_harvest_batch", true);
     if (rc) return rc;
-    if (precision != ESN_F64 && precision != ESN_F32)
-        return fail(-2, "esn_harvest_batch: states are harvested in float64 or float32 only");
     if (!packed_w || !U || !D || !E) return fail(-1, "esn_harvest_batch: null pointer");
     if (n_groups <= 0 || T < 2) return fail(-1, "esn_harvest_batch: invalid sizes (n_groups=%d T=%d)", n_groups, T);
     if (noise_mode == ESN_NOISE_TENSOR && !noise_u) return fail(-1, "esn_harvest_batch: noise tensor missing");

@@ -19,6 +19,8 @@ struct Geometry {
     int Ks;     // LDS row stride in elements (Kp + conflict-avoidance pad)
     int Bt;     // frames per workgroup tile
     int NW, MT, NT;  // waves, row tiles / wave, column tiles / wave (MFMA kernels)
+    int ro_parts;    // readout images per group: 1, or 2 (hi + lo) for fp16/bf16 with n_out > 8
+    int ro_fold;     // fp16/bf16, n_out <= 8: rows 0-7 = hi, rows 8-15 = lo of ONE 16-row image
 };
 
 struct RecurParams {
@@ -48,6 +50,7 @@ struct RecurParams {
     const double* noise_u;
     double noise; int noise_mode; uint64_t seed;
     double* Y; double* E;
+    unsigned long long* stamps;   // diagnostic build (-DESN_STAMPS) only: [block0 wave][8] cycle sums
 };
 
 struct DetectParams {
@@ -86,11 +89,22 @@ __device__ __forceinline__ uint32_t noise_key(uint64_t seed, uint32_t frame, uin
     k = mix32(k ^ (uint32_t)(seed >> 32) ^ (step * 0x85EBCA6BU + 0x27d4eb2fU));
     return k;
 }
-// uniform sample for reservoir row `row` under key `k`, in [0,1) with 16-bit resolution
+// Four uniform bytes for reservoir rows 4*row4 .. 4*row4+3 under key `k`: additive counter,
+// one xorshift32 round and a shift-add/xorshift finaliser (8 full-rate integer ops per 4
+// samples; measured |correlation| < 1.2e-3 across rows / steps / frames).  A pure function of
+// (seed, frame, step, row): every kernel, tiling and rank draws the same noise.
+__device__ __forceinline__ uint32_t noise_quad(uint32_t k, uint32_t row4) {
+    uint32_t s = k + row4 * 0x9E3779B9U;
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    s += s << 3; s ^= s >> 11;
+    return s;
+}
+// uniform in (0,1) with 8-bit resolution for byte `b` (0..3) of a quad: (byte + 0.5) / 256
+__device__ __forceinline__ float noise_byte(uint32_t quad, int b) {
+    return (float)((quad >> (8 * b)) & 0xffU) * (1.0f / 256.0f) + (0.5f / 256.0f);
+}
 __device__ __forceinline__ float noise_uniform(uint32_t k, uint32_t row) {
-    uint32_t h = mix32(k + (row >> 1) * 0x9E3779B9U);
-    uint32_t v = (row & 1) ? (h >> 16) : (h & 0xffffU);
-    return (float)v * (1.0f / 65536.0f) + (0.5f / 65536.0f);
+    return noise_byte(noise_quad(k, row >> 2), (int)(row & 3));
 }
 
 // float32 tanh: odd Taylor polynomial below 0.3 (truncation < 2e-9 relative),
@@ -105,9 +119,28 @@ __device__ __forceinline__ float tanh_f32(float x) {
     p = fmaf(p, x2, -0.333333333333333f);      // -1/3
     p = fmaf(p * x2, x, x);
     float e = __expf(2.0f * ax);                // v_exp_f32 path
-    float r = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);   // v_rcp_f32 (1 ulp), not an IEEE divide
     r = copysignf(r, x);
     return ax < 0.3f ? p : r;
 }
+
+// tanh for the fp16/bf16 kernels.  The packed weights of those kernels are pre-multiplied by
+// ACT_PRESCALE = 2 log2(e), so the accumulator already holds z = 2 log2(e) P and
+//   tanh(P) = 1 - 2 / (1 + 2^z)            (v_exp_f32, v_add, v_rcp_f32, v_fma: 4 instructions)
+// +-inf are handled by the instructions themselves (2^z -> inf -> rcp 0 -> 1; 2^z -> 0 -> -1).
+// Absolute error ~6e-8 (float32 cancellation near 0), far below the 2^-11 relative rounding of
+// the fp16 state the result is stored in.
+constexpr double ACT_PRESCALE = 2.8853900817779268;   // 2 / ln 2
+__device__ __forceinline__ float tanh_prescaled(float z) {
+    float e = __builtin_amdgcn_exp2f(z);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+#ifdef ESN_STAMPS
+#define ESN_STAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ESN_STAMP(var)
+#endif
 
 }  // namespace esn

@@ -57,6 +57,8 @@ __global__ void pack_w_mfma_kernel(const double* W, const double* Win, const dou
         int k = (kg * 32 + 16 * (lane >> 5)) / ES + e;
         double v = wext(W + ws * (size_t)n_res * n_res, Win + ws * (size_t)n_res * n_in,
                         Wfb + ws * (size_t)n_res * n_out, n_res, n_in, n_out, tf, g.kin, g.kfb, row, k);
+        // fp16/bf16 kernels evaluate tanh from 2^z: fold 2 log2(e) into the weights (esn_common.h)
+        if (ES == 2) v *= ACT_PRESCALE;
         out[i] = (T)(float)v;
     }
 }
@@ -65,7 +67,7 @@ __global__ void pack_w_mfma_kernel(const double* W, const double* Win, const dou
 // 16-byte trailer {1/gain, gain, 0, 0} (float).  gain is a power of two that brings
 // max|W_out| of the group to ~2^10 so fp16 images keep full precision; part 1 holds
 // the rounding residual of part 0 (fp16/bf16 only).
-template <typename T, int PARTS>
+template <typename T>
 __global__ __launch_bounds__(256) void pack_wout_mfma_kernel(const double* Wout, int n_res, int n_in,
                                                               int n_out, Geometry g, size_t stride_bytes,
                                                               char* out_base) {
@@ -103,6 +105,8 @@ __global__ __launch_bounds__(256) void pack_wout_mfma_kernel(const double* Wout,
         int ot = (int)(j / nkg64);
         int o = ot * 16 + (lane & 15);
         int k = (kg * 64 + 16 * (lane >> 4)) / ES + e;
+        const bool lo_row = g.ro_fold && o >= 8;        // folded image: rows 8..15 carry the residual
+        if (lo_row) o -= 8;
         double v = 0.0;
         if (o < n_out) {
             if (k < n_res) v = wo[(size_t)o * ncols + k];
@@ -110,11 +114,12 @@ __global__ __launch_bounds__(256) void pack_wout_mfma_kernel(const double* Wout,
         }
         v *= gain;
         T hi = (T)(float)v;
-        img[i] = hi;
-        if (PARTS == 2) img[per_part + i] = (T)(float)(v - (double)(float)hi);
+        T lo = (T)(float)(v - (double)(float)hi);
+        img[i] = lo_row ? lo : hi;
+        if (g.ro_parts == 2) img[per_part + i] = lo;
     }
     if (threadIdx.x == 0) {
-        float* tr = reinterpret_cast<float*>(out + PARTS * per_part * ES);
+        float* tr = reinterpret_cast<float*>(out + g.ro_parts * per_part * ES);
         tr[0] = (float)(1.0 / gain); tr[1] = (float)gain; tr[2] = 0.f; tr[3] = 0.f;
     }
 }
@@ -128,9 +133,8 @@ size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geome
 size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g) {
     if (precision == ESN_F64) return sizeof(double) * (size_t)n_out * (n_res + n_in);
     const int es = (precision == ESN_F32) ? 4 : 2;
-    const int parts = (precision == ESN_F32) ? 1 : 2;
     const int n_ot = (n_out + 15) / 16;
-    return (size_t)parts * n_ot * 16 * g.Kp * es + 16;
+    return (size_t)g.ro_parts * n_ot * 16 * g.Kp * es + 16;
 }
 
 int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g, const double* W,
@@ -167,13 +171,13 @@ int launch_pack_readout(int precision, const esn_shape_t* sh, const Geometry& g,
     }
     char* out = reinterpret_cast<char*>(packed);
     if (precision == ESN_F32)
-        hipLaunchKernelGGL((pack_wout_mfma_kernel<float, 1>), dim3(n_groups), dim3(256), 0, stream, Wout,
+        hipLaunchKernelGGL((pack_wout_mfma_kernel<float>), dim3(n_groups), dim3(256), 0, stream, Wout,
                            sh->n_res, sh->n_in, sh->n_out, g, stride, out);
     else if (precision == ESN_F16)
-        hipLaunchKernelGGL((pack_wout_mfma_kernel<_Float16, 2>), dim3(n_groups), dim3(256), 0, stream, Wout,
+        hipLaunchKernelGGL((pack_wout_mfma_kernel<_Float16>), dim3(n_groups), dim3(256), 0, stream, Wout,
                            sh->n_res, sh->n_in, sh->n_out, g, stride, out);
     else if (precision == ESN_BF16)
-        hipLaunchKernelGGL((pack_wout_mfma_kernel<__bf16, 2>), dim3(n_groups), dim3(256), 0, stream, Wout,
+        hipLaunchKernelGGL((pack_wout_mfma_kernel<__bf16>), dim3(n_groups), dim3(256), 0, stream, Wout,
                            sh->n_res, sh->n_in, sh->n_out, g, stride, out);
     else
         return -1;

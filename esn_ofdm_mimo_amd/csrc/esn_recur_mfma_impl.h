@@ -1,0 +1,518 @@
+// MFMA recurrence kernels (float32 / fp16 / bf16 operands, float32 accumulate).
+//
+// One workgroup owns a tile of Bt = 32*NT sequences for all S timesteps; nothing
+// leaves the CU between steps.  Per step:
+//
+//   phase G1 P  = Wext[:, state k] * X_s                 Z = [X_s ; U_s ; F_s] lives in LDS as
+//            Y_s = yU_{s-1} + Wout[:, state k] * X_s    Zt[frame][k] (k contiguous) = B operand
+//            A operands (Wext, and Wout of the column's group) are pre-packed in MFMA
+//            fragment order and streamed from L2 inside the same k-loop; wave w owns rows
+//            [32*MT*w, 32*MT*(w+1)) x all Bt columns of P, and -- as "column owner" c = w <
+//            Bt/16 -- the 16x16 readout tile of frames 16c..16c+15.
+//            owners: F_s <- Y_s into Zt, unscaled Y_s -> HBM (row s-1, if past the transient)
+//   barrier  (F_s visible)                                    [skipped when harvesting]
+//   phase G2 P += Wext[:, input+feedback k] * [U_s ; F_s];  owners: yU_s = Wout[:, input k] * U_s
+//   barrier  (all reads of Zt done)
+//   phase E  X_{s+1} = tanh(P) + noise*(u-0.5) -> Zt state rows;  owners: U_{s+1} (prefetched at
+//            the top of the step) and, when harvesting, the teacher F_{s+1} -> Zt
+//   barrier
+// after the last step the owners run one more readout pass for Y_S.  The readout therefore
+// costs 16x16 MFMAs inside the GEMM loop instead of a serial chain of L2 loads per step.
+//
+// K is consumed in 32-byte groups of each LDS row: lane (r = lane&31, h = lane>>5)
+// takes bytes [32*kg + 16*h, +16) of row r of both operands, so one ds_read_b128 /
+// one 16-byte global load feeds 4 x v_mfma_f32_32x32x2_f32 (float32) or
+// 1 x v_mfma_f32_32x32x16_{f16,bf16}.  (The k order inside a group is a fixed
+// permutation applied to both operands, which a dot product does not see.)
+#pragma once
+#include "esn_common.h"
+
+namespace esn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+
+struct TraitsF32 {
+    typedef float elem;
+    static constexpr int ES = 4;
+    static constexpr int PARTS = 1;   // readout images (1 = W_out as is)
+    static __device__ __forceinline__ void mma32(f32x16& c, u32x4 a, u32x4 b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const uint32_t ai = a[i], bi = b[i];   // copy out: bit_cast of a vector element lvalue reads lane 0
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(ai), __uint_as_float(bi), c, 0, 0, 0);
+        }
+    }
+    // 64-byte row group, lane quarter q takes 16 B: 4 x (16x16x4)
+    static __device__ __forceinline__ void mma16(f32x4& c, u32x4 a, u32x4 b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const uint32_t ai = a[i], bi = b[i];
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ai), __uint_as_float(bi), c, 0, 0, 0);
+        }
+    }
+    static __device__ __forceinline__ void store4(char* dst, float v0, float v1, float v2, float v3) {
+        f32x4 v = {v0, v1, v2, v3};
+        *reinterpret_cast<f32x4*>(dst) = v;
+    }
+    static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<float*>(dst) = v; }
+    static __device__ __forceinline__ float load1(const char* src) { return *reinterpret_cast<const float*>(src); }
+    static __device__ __forceinline__ float act(float x) { return tanh_f32(x); }
+};
+
+struct TraitsF16 {
+    typedef _Float16 elem;
+    static constexpr int ES = 2;
+    static constexpr int PARTS = 2;   // W_out = hi + lo (two fp16 images)
+    static __device__ __forceinline__ void mma32(f32x16& c, u32x4 a, u32x4 b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a),
+                                                   __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma16(f32x4& c, u32x4 a, u32x4 b) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a),
+                                                   __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store4(char* dst, float v0, float v1, float v2, float v3) {
+        h16x4 v = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+        *reinterpret_cast<h16x4*>(dst) = v;
+    }
+    static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<_Float16*>(dst) = (_Float16)v; }
+    static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const _Float16*>(src); }
+    static __device__ __forceinline__ float act(float z) { return tanh_prescaled(z); }   // weights carry 2 log2 e
+};
+
+struct TraitsBF16 {
+    typedef __bf16 elem;
+    static constexpr int ES = 2;
+    static constexpr int PARTS = 2;
+    static __device__ __forceinline__ void mma32(f32x16& c, u32x4 a, u32x4 b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a),
+                                                    __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma16(f32x4& c, u32x4 a, u32x4 b) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b16x8, a),
+                                                    __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store4(char* dst, float v0, float v1, float v2, float v3) {
+        b16x4 v = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+        *reinterpret_cast<b16x4*>(dst) = v;
+    }
+    static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<__bf16*>(dst) = (__bf16)v; }
+    static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const __bf16*>(src); }
+    static __device__ __forceinline__ float act(float z) { return tanh_prescaled(z); }   // weights carry 2 log2 e
+};
+
+template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE>
+__global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
+    extern __shared__ __attribute__((aligned(16))) char zt[];   // Zt[Bt][Ks] elements
+    constexpr int ES = TR::ES;
+    constexpr int BT = 32 * NT;
+    constexpr int NTHREADS = NW * 64;
+    constexpr int NOWN = BT / 16;            // column-owner waves
+    constexpr int MAX_OT = 1;                // readout row tiles of 16 (n_out <= 16)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const Geometry& g = p.g;
+    const int n_res = p.n_res, n_in = p.n_in, n_out = p.n_out;
+    const int row_bytes = g.Ks * ES;
+    const int nkg = g.Kp * ES / 32;          // 32-byte k-groups per row
+    const int nkgS = g.Mp * ES / 32;         // ... of which state rows
+    const int nk64 = nkg / 2;                // 64-byte groups (readout MFMA granularity)
+    const int nk64S = nkgS / 2;
+
+    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int slot0 = tile * BT;
+    const int grp0 = slot0 / p.Fpad;
+    if (grp0 >= p.n_groups) return;
+    const int wset = grp0 % p.n_wsets;
+    const char* wp = reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride
+                     + ((size_t)(wave * MT) * nkg * 64 + lane) * 16;
+    const int n_ot = (n_out + 15) / 16;
+    const int out_rows = p.S - p.transient;
+    const int ncols = n_res + n_in;
+
+    // frame of the column this lane owns in each 32-wide column tile (GEMM layout)
+    int col_fr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { int gtmp; col_fr[nt] = slot_frame(p, slot0 + nt * 32 + r, gtmp); }
+    // column-owner view: wave c < NOWN owns frames 16c..16c+15 (one group: Fpad % 16 == 0)
+    const bool owner = wave < NOWN;
+    const int oq = lane >> 4, ofc = lane & 15;
+    const int of = (owner ? wave : 0) * 16 + ofc;            // tile-local frame of this owner lane
+    int ro_grp = 0;
+    const int ro_fr = slot_frame(p, slot0 + of, ro_grp);
+    const char* wop = nullptr;
+    float wo_inv = 1.f;
+    if (!HARVEST && owner) {
+        const int cg = (slot0 + wave * 16) / p.Fpad;
+        if (cg < p.n_groups) {
+            const char* base = reinterpret_cast<const char*>(p.packed_wout) + (size_t)cg * p.wout_stride;
+            wop = base + (size_t)lane * 16;
+            wo_inv = *reinterpret_cast<const float*>(base + (size_t)g.ro_parts * n_ot * nk64 * 1024);
+        }
+    }
+    const bool do_ro = (wop != nullptr);
+    float un_inv[4] = {1.f, 1.f, 1.f, 1.f}, un_sh[4] = {0.f, 0.f, 0.f, 0.f};   // y_unscaled = (y - sh) * inv
+    if (do_ro && ro_fr >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = 4 * oq + j;
+            if (o < n_out) {
+                if (p.t_scale) un_inv[j] = (float)(1.0 / p.t_scale[(size_t)ro_grp * n_out + o]);
+                if (p.t_shift) un_sh[j] = (float)p.t_shift[(size_t)ro_grp * n_out + o];
+            }
+        }
+    }
+    // per-lane unscale constants for the 4 outputs o = 16*ot + 4*oq + j this lane stores
+    // (kept as scale/shift loads at the store: rare enough)
+
+    // ---- LDS init: state rows, padding, initial feedback -----------------------
+    for (int i = tid; i < BT * g.Ks; i += NTHREADS) {
+        int f = i / g.Ks, k = i % g.Ks;
+        float v = 0.f;
+        int pg;
+        const int fr = slot_frame(p, slot0 + f, pg);
+        if (fr >= 0) {
+            if (k < n_res) {
+                if (p.x0) v = (float)p.x0[(size_t)pg * n_res + k];
+            } else if (k >= g.kfb && k < g.kfb + n_out && !HARVEST) {
+                if (p.y0) v = (float)p.y0[(size_t)pg * n_out + (k - g.kfb)];
+            }
+        }
+        TR::store1(zt + (size_t)i * ES, v);
+    }
+    __syncthreads();
+
+    // owners stage the inputs of recurrence step s (input row s + in_row_off) for their 16
+    // frames; when harvesting also the teacher row s and the input columns of E
+    const int kin_p = g.kfb - g.kin;
+    const int kfb_p = round_up(n_out, 4);
+    auto load_in = [&](int s, int i) -> float {       // element i of this wave's 16 x kin_p block
+        const int f = (owner ? wave : 0) * 16 + i / kin_p, c = i % kin_p;
+        int pg;
+        const int fr = slot_frame(p, slot0 + f, pg);
+        float v = 0.f;
+        if (fr >= 0 && c < n_in) {
+            const int row = s + p.in_row_off;
+            double raw = (row < p.T_in) ? p.U[((size_t)fr * p.T_in + row) * n_in + c] : 0.0;
+            double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + c] : 1.0;
+            double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + c] : 0.0;
+            double sv = raw * sc + sh;
+            if (HARVEST) p.E[((size_t)fr * (p.S + 1) + row) * ncols + n_res + c] = sv;
+            v = (float)sv;
+        }
+        return v;
+    };
+    auto store_in = [&](int i, float v) {
+        const int f = (owner ? wave : 0) * 16 + i / kin_p, c = i % kin_p;
+        TR::store1(zt + (size_t)f * row_bytes + (size_t)(g.kin + c) * ES, v);
+    };
+    auto stage_teacher = [&](int s) {
+        for (int i = lane; i < 16 * kfb_p; i += 64) {
+            const int f = wave * 16 + i / kfb_p, c = i % kfb_p;
+            int pg;
+            const int fr = slot_frame(p, slot0 + f, pg);
+            float v = 0.f;
+            if (fr >= 0 && c < n_out) {
+                double raw = p.D[((size_t)fr * (p.S + 1) + s) * n_out + c];
+                double sc = p.t_scale ? p.t_scale[(size_t)pg * n_out + c] : 1.0;
+                double sh = p.t_shift ? p.t_shift[(size_t)pg * n_out + c] : 0.0;
+                v = (float)(raw * sc + sh);
+            }
+            TR::store1(zt + (size_t)f * row_bytes + (size_t)(g.kfb + c) * ES, v);
+        }
+    };
+    constexpr int NIN = 4;                       // prefetch registers: 16*kin_p <= 64*NIN
+    const bool in_fits = 16 * kin_p <= 64 * NIN &&
+                         (unsigned long long)p.n_frames * p.T_in * n_in < 0xffffffffULL;
+    // fast path constants: element lane + 64 j of this owner's 16 x kin_p block -> byte offset of
+    // U[fr][0][c] (or ~0 when padding) and float scale / shift of its group
+    uint32_t in_off[NIN];                        // in doubles; host guarantees the batch fits 32 bits
+    float in_sc[NIN], in_sh[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+        const int i = lane + 64 * j;
+        const int f = (owner ? wave : 0) * 16 + i / kin_p, c = i % kin_p;
+        int pg;
+        const int fr = slot_frame(p, slot0 + f, pg);
+        in_off[j] = ~0U; in_sc[j] = 0.f; in_sh[j] = 0.f;
+        if (owner && i < 16 * kin_p && fr >= 0 && c < n_in) {
+            in_off[j] = (uint32_t)fr * (uint32_t)(p.T_in * n_in) + (uint32_t)c;
+            in_sc[j] = p.in_scale ? (float)p.in_scale[(size_t)pg * n_in + c] : 1.f;
+            in_sh[j] = p.in_shift ? (float)p.in_shift[(size_t)pg * n_in + c] : 0.f;
+        }
+    }
+    auto load_in_fast = [&](int s, int j) -> float {
+        const int row = s + p.in_row_off;
+        float v = 0.f;
+        if (in_off[j] != ~0U) {
+            double raw = (row < p.T_in) ? p.U[(size_t)in_off[j] + (size_t)row * n_in] : 0.0;
+            v = fmaf((float)raw, in_sc[j], in_sh[j]);
+        }
+        return v;
+    };
+    if (owner) {
+        for (int i = lane; i < 16 * kin_p; i += 64) store_in(i, load_in(0, i));
+        if (HARVEST) {
+            stage_teacher(0);
+            // E row 0 = [0, scale(u[0])]  (pyESN.py:179,189): state part; input part via row -1+1
+            for (int i = lane; i < 16 * ncols; i += 64) {
+                const int f = wave * 16 + i / ncols, c = i % ncols;
+                int pg;
+                const int fr = slot_frame(p, slot0 + f, pg);
+                if (fr < 0) continue;
+                double v = 0.0;
+                if (c >= n_res) {
+                    const int ci = c - n_res;
+                    double raw = p.U[((size_t)fr * p.T_in) * n_in + ci];
+                    double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + ci] : 1.0;
+                    double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + ci] : 0.0;
+                    v = raw * sc + sh;
+                }
+                p.E[((size_t)fr * (p.S + 1)) * ncols + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    const float noise = (float)p.noise;
+    const float n_c1 = noise * (1.0f / 256.0f), n_c0 = noise * (0.5f / 256.0f - 0.5f);
+    const char* bbase = zt + (size_t)r * row_bytes + 16 * h;
+    const char* zrow = zt + (size_t)of * row_bytes + 16 * oq;      // owner readout B rows
+    f32x4 yacc[MAX_OT];                                              // running readout (owners)
+#pragma unroll
+    for (int ot = 0; ot < MAX_OT; ++ot) yacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // readout over 64-byte groups [k0, k1) of this owner's 16 frames, accumulating into yacc
+    auto readout_groups = [&](int k0, int k1) {
+        for (int kk = k0; kk < k1; ++kk) {
+            const u32x4 rb = *reinterpret_cast<const u32x4*>(zrow + kk * 64);
+#pragma unroll
+            for (int ot = 0; ot < MAX_OT; ++ot) {
+                if (ot < n_ot) {
+                    for (int part = 0; part < g.ro_parts; ++part) {
+                        const u32x4 ra = *reinterpret_cast<const u32x4*>(
+                            wop + ((size_t)(part * n_ot + ot) * nk64 + kk) * 1024);
+                        TR::mma16(yacc[ot], ra, rb);
+                    }
+                }
+            }
+        }
+    };
+    // Y complete: feedback rows into Zt, unscaled output row `orow` to HBM, reset yacc
+    auto finish_readout = [&](int orow, bool write_fb) {
+#pragma unroll
+        for (int ot = 0; ot < MAX_OT; ++ot) {
+            if (ot < n_ot) {
+                f32x4 y = yacc[ot];
+                if (g.ro_fold) {          // rows 8..15 (lanes 32..63) hold the residual image's product
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] += __shfl_xor(y[j], 32);
+                }
+                y *= wo_inv;
+                const int o0 = ot * 16 + 4 * oq;
+                if (o0 < kfb_p) {
+                    if (write_fb)
+                        TR::store4(zt + (size_t)of * row_bytes + (size_t)(g.kfb + o0) * ES, y[0], y[1], y[2], y[3]);
+                    if (orow >= 0 && ro_fr >= 0) {
+                        double* yo = p.Y + ((size_t)ro_fr * out_rows + orow) * n_out;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int o = o0 + j;
+                            if (o < n_out) yo[o] = (double)((y[j] - un_sh[j]) * un_inv[j]);
+                        }
+                    }
+                }
+                yacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+#ifdef ESN_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    for (int s = 0; s < p.S; ++s) {
+        ESN_STAMP(t0)
+        // next step's input rows: issue the HBM loads now, park them in registers
+        float in_next[NIN];
+        const bool have_next = owner && (s + 1 < p.S);
+        if (have_next && in_fits) {
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                in_next[j] = HARVEST ? ((lane + 64 * j < 16 * kin_p) ? load_in(s + 1, lane + 64 * j) : 0.f)
+                                     : load_in_fast(s + 1, j);
+            }
+        }
+        // ================= phase G1: state k-groups (+ readout of Y_s) ===========
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+        u32x4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            a_cur[mt] = *reinterpret_cast<const u32x4*>(wp + (size_t)mt * nkg * 1024);
+        auto main_groups = [&](int k0, int k1) {
+            for (int kg = k0; kg < k1; ++kg) {
+                const int kn = (kg + 1 < nkg) ? kg + 1 : kg;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    a_nxt[mt] = *reinterpret_cast<const u32x4*>(wp + ((size_t)mt * nkg + kn) * 1024);
+                u32x4 b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    b[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + kg * 32);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) TR::mma32(acc[mt][nt], a_cur[mt], b[nt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+            }
+        };
+        const bool ro_now = do_ro && s > 0;
+        if (ro_now) {
+            for (int kk = 0; kk < nk64S; ++kk) {
+                main_groups(2 * kk, 2 * kk + 2);
+                readout_groups(kk, kk + 1);
+            }
+            finish_readout(s - 1 - p.transient, true);
+        } else {
+            main_groups(0, nkgS);
+        }
+        ESN_STAMP(t1)
+        if (!HARVEST) __syncthreads();          // F_s visible to every wave
+        ESN_STAMP(t2)
+        // ================= phase G2: input + feedback k-groups =====================
+        main_groups(nkgS, nkg);
+        if (do_ro) readout_groups(nk64S, nk64);   // yU_s (feedback columns carry zero weights)
+        ESN_STAMP(t3)
+        __syncthreads();                          // every wave has finished reading Z_s
+        ESN_STAMP(t4)
+
+        // ================= phase E: X_{s+1} = tanh(P) + noise =====================
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = nt * 32 + r;
+            const int fr = col_fr[nt];
+            uint32_t key = 0;
+            const double* nz = nullptr;
+            if (NOISE == ESN_NOISE_COUNTER)
+                key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
+            if (NOISE == ESN_NOISE_TENSOR && fr >= 0)
+                nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = (wave * MT + mt) * 32 + 8 * q + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[mt][nt][4 * q + j]);
+                    // (state rows >= n_res are padding: their columns of Wext / W_out are zero, so the
+                    //  noise they pick up is never read -- no masking needed)
+                    if (NOISE == ESN_NOISE_COUNTER) {
+                        // row/4 = (wave*MT*8 + h) + (mt*8 + 2q): the second term folds at compile time
+                        uint32_t sq = key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U;
+                        sq ^= sq << 13; sq ^= sq >> 17; sq ^= sq << 5;
+                        sq += sq << 3; sq ^= sq >> 11;
+                        // + noise*((byte+0.5)/256 - 0.5) = byte*n_c1 + n_c0
+                        v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
+                        v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
+                        v[2] = fmaf((float)((sq >> 16) & 0xffU), n_c1, v[2] + n_c0);
+                        v[3] = fmaf((float)(sq >> 24), n_c1, v[3] + n_c0);
+                    } else if (NOISE == ESN_NOISE_TENSOR) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+                    }
+                    TR::store4(zt + (size_t)col * row_bytes + (size_t)row * ES, v[0], v[1], v[2], v[3]);
+                }
+                // keep the scheduler from interleaving all 16*MT*NT activations (register pressure)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (have_next) {
+            if (in_fits) {
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const int i = lane + 64 * j;
+                    if (i < 16 * kin_p) store_in(i, in_next[j]);
+                }
+            } else {
+                for (int i = lane; i < 16 * kin_p; i += 64) store_in(i, load_in(s + 1, i));
+            }
+            if (HARVEST) stage_teacher(s + 1);
+        }
+        ESN_STAMP(t5)
+        __syncthreads();                          // X_{s+1}, U_{s+1} (, F_{s+1}) complete
+        ESN_STAMP(t6)
+        if (HARVEST) {
+            // E row s+1, state columns, straight from the LDS image: wave w copies frames w, w+NW, ...
+            for (int f = wave; f < BT; f += NW) {
+                int pg;
+                const int fr = slot_frame(p, slot0 + f, pg);
+                if (fr < 0) continue;
+                double* er = p.E + ((size_t)fr * (p.S + 1) + (s + 1)) * ncols;
+                const char* zr = zt + (size_t)f * row_bytes;
+                for (int c = lane; c < n_res; c += 64) er[c] = (double)TR::load1(zr + (size_t)c * ES);
+            }
+        }
+#ifdef ESN_STAMPS
+        st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2;
+        st_acc[3] += t4 - t3; st_acc[4] += t5 - t4; st_acc[5] += t6 - t5;
+#endif
+    }
+    // final readout Y_S = yU_{S-1} + Wout_x X_S
+    if (do_ro) {
+        readout_groups(0, nk64S);
+        finish_readout(p.S - 1 - p.transient, false);
+    }
+#ifdef ESN_STAMPS
+    if (p.stamps && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 6; ++i) p.stamps[wave * 8 + i] = st_acc[i];
+#endif
+}
+
+// ---- host side: geometry choice and launch -------------------------------------
+
+template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE>
+static int launch_k(const RecurParams& p, hipStream_t stream) {
+    size_t lds = (size_t)p.g.Bt * p.g.Ks * TR::ES;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE>), dim3(p.n_tiles), dim3(NW * 64), lds,
+                       stream, p);
+    return (int)hipGetLastError();
+}
+
+template <typename TR, int NW, int MT, int NT, bool HARVEST>
+static int launch_n(const RecurParams& p, hipStream_t stream) {
+    switch (p.noise_mode) {
+        case ESN_NOISE_NONE: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_NONE>(p, stream);
+        case ESN_NOISE_TENSOR: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_TENSOR>(p, stream);
+        default: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_COUNTER>(p, stream);
+    }
+}
+
+template <typename TR, int NW, int MT, int NT>
+static int launch_one(const RecurParams& p, hipStream_t stream) {
+    return p.harvest ? launch_n<TR, NW, MT, NT, true>(p, stream) : launch_n<TR, NW, MT, NT, false>(p, stream);
+}
+
+}  // namespace esn

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a timestep of the predict kernel spend its cycles?  Loads the
+-DESN_STAMPS build (libesn_hip_stamps.so), runs one predict launch of the bench workload and
+prints, per wave of workgroup 0, the summed s_memtime cycles of each phase.  Shares only:
+the stamped build forbids overlaps the real kernel has (guide 7, In-kernel stamps)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from esn_ofdm_mimo_amd import _lib, build  # noqa: E402
+
+build.build_library(stamps=True, verbose=False)
+_lib.LIB_PATH = os.path.join(ROOT, "esn_ofdm_mimo_amd", "libesn_hip_stamps.so")
+from esn_ofdm_mimo_amd.montecarlo import DetectorSweep, LinkParams  # noqa: E402
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16"
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+params = LinkParams()
+F = params.coherence_symbols
+sweep = DetectorSweep(params, n_reservoir=512, noise=0.001, seed=1, precision=prec, fit_precision="f32")
+lib = _lib.load()
+lib.esn_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+buf = torch.zeros(16 * 8, dtype=torch.int64, device="cuda")
+lib.esn_debug_set_stamp_buffer(buf.data_ptr())
+data = sweep.src.blocks_fast(12.0, 0, 0, G, F)
+sweep.set_snr(12.0, G)
+sweep.train(data["pilot_y"], data["pilot_x"], seed=1)
+U = torch.view_as_real(data["data_y"]).reshape(G * F, params.t_frame, sweep.n_in)
+T = params.t_frame + params.delay
+for _ in range(2):
+    sweep.bank.predict(U, F, T=T, transient=params.delay + params.cp, precision=prec, noise_mode="counter", seed=3)
+torch.cuda.synchronize()
+st = buf.cpu().numpy().reshape(16, 8)[:8, :6].astype(float) / T
+names = ["G1 gemm+ro", "wait Ba", "G2 in+fb", "wait Bb", "E act+noise", "wait Bc"]
+print(f"precision {prec}: cycles per timestep (workgroup 0), per wave")
+print("wave " + " ".join(f"{n:>13s}" for n in names) + "        total")
+for w in range(8):
+    print(f"{w:4d} " + " ".join(f"{v:13.0f}" for v in st[w]) + f" {st[w].sum():12.0f}")
+print("mean " + " ".join(f"{v:13.0f}" for v in st.mean(0)) + f" {st.mean(0).sum():12.0f}")
