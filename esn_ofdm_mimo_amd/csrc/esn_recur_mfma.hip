@@ -1,5 +1,7 @@
 // Geometry table and precision dispatch of the MFMA recurrence kernels; the kernels themselves are
 // instantiated per precision in esn_recur_mfma_{f32,f16,bf16}.hip (compiled in parallel).
+#include <stdio.h>
+#include <stdlib.h>
 #include "esn_common.h"
 
 namespace esn {
@@ -28,8 +30,14 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
         else if (n_res <= 2048) { NW = 16; MT = 4; NT = 1; }
         else return false;
     }
+    // tuning knob (benchmarks only): ESN_MFMA_GEOM="NW,MT,NT" overrides the fp16/bf16 predict table
+    if (!harvest && es == 2) {
+        const char* ov = getenv("ESN_MFMA_GEOM");
+        int a, b, c;
+        if (ov && sscanf(ov, "%d,%d,%d", &a, &b, &c) == 3 && 32 * a * b >= n_res) { NW = a; MT = b; NT = c; }
+    }
     // harvest: one pilot per trained ESN -> few sequences; a 32-frame tile spreads them over more CUs
-    if (harvest && n_res > 256 && n_res <= 512) NT = 1;
+    if (harvest && n_res > 256 && n_res <= 512) { NW = 8; MT = 2; NT = 1; }
     if (n_out > 16) return false;
     g->NW = NW; g->MT = MT; g->NT = NT;
     g->Mp = 32 * MT * NW;
@@ -42,7 +50,9 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
     g->Bt = 32 * NT;
     g->ro_fold = (es == 2 && n_out <= 8) ? 1 : 0;
     g->ro_parts = (es == 2 && !g->ro_fold) ? 2 : 1;
-    return (size_t)g->Bt * g->Ks * es <= 160 * 1024;
+    // Zt image + the small frame / scale tables behind it (esn_recur_mfma_impl.h)
+    const size_t tables = 4 * (size_t)g->Bt + 8 * (size_t)(g->Bt / 16) * ((g->kfb - g->kin) + 16);
+    return (size_t)g->Bt * g->Ks * es + tables <= 160 * 1024;
 }
 
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream) {

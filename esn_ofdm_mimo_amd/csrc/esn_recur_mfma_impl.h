@@ -112,12 +112,12 @@ struct TraitsBF16 {
 
 template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE>
 __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
-    extern __shared__ __attribute__((aligned(16))) char zt[];   // Zt[Bt][Ks] elements
+    extern __shared__ __attribute__((aligned(16))) char zt[];   // Zt[Bt][Ks] elements, then tables
     constexpr int ES = TR::ES;
     constexpr int BT = 32 * NT;
     constexpr int NTHREADS = NW * 64;
-    constexpr int NOWN = BT / 16;            // column-owner waves
-    constexpr int MAX_OT = 1;                // readout row tiles of 16 (n_out <= 16)
+    constexpr int NOWN = BT / 16;                       // 16-frame column tiles of the workgroup
+    constexpr int OC = (NOWN + NW - 1) / NW;            // column tiles owned per wave: c = wave + i*NW
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,6 +129,11 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     const int nkgS = g.Mp * ES / 32;         // ... of which state rows
     const int nk64 = nkg / 2;                // 64-byte groups (readout MFMA granularity)
     const int nk64S = nkgS / 2;
+    const int kin_p = g.kfb - g.kin;
+    const int kfb_p = round_up(n_out, 4);
+    const int n_ot = (n_out + 15) / 16;      // == 1 (mfma_geometry rejects n_out > 16)
+    const int out_rows = p.S - p.transient;
+    const int ncols = n_res + n_in;
 
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
     const int slot0 = tile * BT;
@@ -137,45 +142,35 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     const int wset = grp0 % p.n_wsets;
     const char* wp = reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride
                      + ((size_t)(wave * MT) * nkg * 64 + lane) * 16;
-    const int n_ot = (n_out + 15) / 16;
-    const int out_rows = p.S - p.transient;
-    const int ncols = n_res + n_in;
 
-    // frame of the column this lane owns in each 32-wide column tile (GEMM layout)
-    int col_fr[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { int gtmp; col_fr[nt] = slot_frame(p, slot0 + nt * 32 + r, gtmp); }
-    // column-owner view: wave c < NOWN owns frames 16c..16c+15 (one group: Fpad % 16 == 0)
-    const bool owner = wave < NOWN;
-    const int oq = lane >> 4, ofc = lane & 15;
-    const int of = (owner ? wave : 0) * 16 + ofc;            // tile-local frame of this owner lane
-    int ro_grp = 0;
-    const int ro_fr = slot_frame(p, slot0 + of, ro_grp);
-    const char* wop = nullptr;
-    float wo_inv = 1.f;
-    if (!HARVEST && owner) {
-        const int cg = (slot0 + wave * 16) / p.Fpad;
-        if (cg < p.n_groups) {
-            const char* base = reinterpret_cast<const char*>(p.packed_wout) + (size_t)cg * p.wout_stride;
-            wop = base + (size_t)lane * 16;
-            wo_inv = *reinterpret_cast<const float*>(base + (size_t)g.ro_parts * n_ot * nk64 * 1024);
+    // small per-tile tables behind the Zt image (instead of per-lane registers):
+    //   tab_fr[BT]            frame index of each tile-local frame (-1 = padding slot)
+    //   tab_in[NOWN][kin_p]   {scale, shift} of the column tile's group, per input column
+    //   tab_un[NOWN][16]      {1/t_scale, t_shift} of the column tile's group, per output
+    int* tab_fr = reinterpret_cast<int*>(zt + (size_t)BT * row_bytes);
+    float2* tab_in = reinterpret_cast<float2*>(tab_fr + BT);
+    float2* tab_un = tab_in + NOWN * kin_p;
+    for (int i = tid; i < BT; i += NTHREADS) { int gtmp; tab_fr[i] = slot_frame(p, slot0 + i, gtmp); }
+    for (int i = tid; i < NOWN * kin_p; i += NTHREADS) {
+        const int c16 = i / kin_p, c = i % kin_p;
+        const int cg = (slot0 + c16 * 16) / p.Fpad;
+        float2 v = make_float2(0.f, 0.f);
+        if (cg < p.n_groups && c < n_in) {
+            v.x = p.in_scale ? (float)p.in_scale[(size_t)cg * n_in + c] : 1.f;
+            v.y = p.in_shift ? (float)p.in_shift[(size_t)cg * n_in + c] : 0.f;
         }
+        tab_in[i] = v;
     }
-    const bool do_ro = (wop != nullptr);
-    float un_inv[4] = {1.f, 1.f, 1.f, 1.f}, un_sh[4] = {0.f, 0.f, 0.f, 0.f};   // y_unscaled = (y - sh) * inv
-    if (do_ro && ro_fr >= 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = 4 * oq + j;
-            if (o < n_out) {
-                if (p.t_scale) un_inv[j] = (float)(1.0 / p.t_scale[(size_t)ro_grp * n_out + o]);
-                if (p.t_shift) un_sh[j] = (float)p.t_shift[(size_t)ro_grp * n_out + o];
-            }
+    for (int i = tid; i < NOWN * 16; i += NTHREADS) {
+        const int c16 = i / 16, o = i % 16;
+        const int cg = (slot0 + c16 * 16) / p.Fpad;
+        float2 v = make_float2(1.f, 0.f);
+        if (cg < p.n_groups && o < n_out) {
+            if (p.t_scale) v.x = (float)(1.0 / p.t_scale[(size_t)cg * n_out + o]);
+            if (p.t_shift) v.y = (float)p.t_shift[(size_t)cg * n_out + o];
         }
+        tab_un[i] = v;
     }
-    // per-lane unscale constants for the 4 outputs o = 16*ot + 4*oq + j this lane stores
-    // (kept as scale/shift loads at the store: rare enough)
-
     // ---- LDS init: state rows, padding, initial feedback -----------------------
     for (int i = tid; i < BT * g.Ks; i += NTHREADS) {
         int f = i / g.Ks, k = i % g.Ks;
@@ -193,84 +188,92 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     }
     __syncthreads();
 
-    // owners stage the inputs of recurrence step s (input row s + in_row_off) for their 16
-    // frames; when harvesting also the teacher row s and the input columns of E
-    const int kin_p = g.kfb - g.kin;
-    const int kfb_p = round_up(n_out, 4);
-    auto load_in = [&](int s, int i) -> float {       // element i of this wave's 16 x kin_p block
-        const int f = (owner ? wave : 0) * 16 + i / kin_p, c = i % kin_p;
-        int pg;
-        const int fr = slot_frame(p, slot0 + f, pg);
-        float v = 0.f;
-        if (fr >= 0 && c < n_in) {
-            const int row = s + p.in_row_off;
-            double raw = (row < p.T_in) ? p.U[((size_t)fr * p.T_in + row) * n_in + c] : 0.0;
-            double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + c] : 1.0;
-            double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + c] : 0.0;
-            double sv = raw * sc + sh;
-            if (HARVEST) p.E[((size_t)fr * (p.S + 1) + row) * ncols + n_res + c] = sv;
-            v = (float)sv;
-        }
-        return v;
-    };
-    auto store_in = [&](int i, float v) {
-        const int f = (owner ? wave : 0) * 16 + i / kin_p, c = i % kin_p;
-        TR::store1(zt + (size_t)f * row_bytes + (size_t)(g.kin + c) * ES, v);
-    };
-    auto stage_teacher = [&](int s) {
-        for (int i = lane; i < 16 * kfb_p; i += 64) {
-            const int f = wave * 16 + i / kfb_p, c = i % kfb_p;
-            int pg;
-            const int fr = slot_frame(p, slot0 + f, pg);
-            float v = 0.f;
-            if (fr >= 0 && c < n_out) {
-                double raw = p.D[((size_t)fr * (p.S + 1) + s) * n_out + c];
-                double sc = p.t_scale ? p.t_scale[(size_t)pg * n_out + c] : 1.0;
-                double sh = p.t_shift ? p.t_shift[(size_t)pg * n_out + c] : 0.0;
-                v = (float)(raw * sc + sh);
-            }
-            TR::store1(zt + (size_t)f * row_bytes + (size_t)(g.kfb + c) * ES, v);
-        }
-    };
-    constexpr int NIN = 4;                       // prefetch registers: 16*kin_p <= 64*NIN
-    const bool in_fits = 16 * kin_p <= 64 * NIN &&
-                         (unsigned long long)p.n_frames * p.T_in * n_in < 0xffffffffULL;
-    // fast path constants: element lane + 64 j of this owner's 16 x kin_p block -> byte offset of
-    // U[fr][0][c] (or ~0 when padding) and float scale / shift of its group
-    uint32_t in_off[NIN];                        // in doubles; host guarantees the batch fits 32 bits
-    float in_sc[NIN], in_sh[NIN];
+    // ---- column ownership: wave owns tiles c_i = wave + i*NW (i < OC) of 16 frames each ------
+    // readout view of a lane inside a 16x16 tile: frame column ofc, output rows 4*oq .. 4*oq+3
+    const int oq = lane >> 4, ofc = lane & 15;
+    const char* wop[OC];          // this group's packed W_out (+ lane offset), nullptr = no readout
+    float wo_inv[OC];
+    bool own[OC];
 #pragma unroll
-    for (int j = 0; j < NIN; ++j) {
-        const int i = lane + 64 * j;
-        const int f = (owner ? wave : 0) * 16 + i / kin_p, c = i % kin_p;
-        int pg;
-        const int fr = slot_frame(p, slot0 + f, pg);
-        in_off[j] = ~0U; in_sc[j] = 0.f; in_sh[j] = 0.f;
-        if (owner && i < 16 * kin_p && fr >= 0 && c < n_in) {
-            in_off[j] = (uint32_t)fr * (uint32_t)(p.T_in * n_in) + (uint32_t)c;
-            in_sc[j] = p.in_scale ? (float)p.in_scale[(size_t)pg * n_in + c] : 1.f;
-            in_sh[j] = p.in_shift ? (float)p.in_shift[(size_t)pg * n_in + c] : 0.f;
+    for (int i = 0; i < OC; ++i) {
+        const int c = wave + i * NW;
+        own[i] = c < NOWN;
+        wop[i] = nullptr; wo_inv[i] = 1.f;
+        if (!HARVEST && own[i]) {
+            const int cg = (slot0 + c * 16) / p.Fpad;
+            if (cg < p.n_groups) {
+                const char* base = reinterpret_cast<const char*>(p.packed_wout) + (size_t)cg * p.wout_stride;
+                wop[i] = base + (size_t)lane * 16;
+                wo_inv[i] = *reinterpret_cast<const float*>(base + (size_t)g.ro_parts * n_ot * nk64 * 1024);
+            }
         }
     }
-    auto load_in_fast = [&](int s, int j) -> float {
-        const int row = s + p.in_row_off;
+
+    // inputs of recurrence step s (input row s + in_row_off) for owned tile c, element e of its
+    // 16 x kin_p block; when harvesting also writes the input columns of E
+    const uint32_t in_stride = (uint32_t)(p.T_in * n_in);
+    auto load_in = [&](int s, int c, int e) -> float {
+        const int f = c * 16 + e / kin_p, ci = e % kin_p;
+        const int fr = tab_fr[f];
         float v = 0.f;
-        if (in_off[j] != ~0U) {
-            double raw = (row < p.T_in) ? p.U[(size_t)in_off[j] + (size_t)row * n_in] : 0.0;
-            v = fmaf((float)raw, in_sc[j], in_sh[j]);
+        if (fr >= 0 && ci < n_in) {
+            const int row = s + p.in_row_off;
+            double raw = (row < p.T_in) ? p.U[(size_t)fr * in_stride + (size_t)row * n_in + ci] : 0.0;
+            const float2 ss = tab_in[c * kin_p + ci];
+            if (HARVEST) {
+                int pg;
+                slot_frame(p, slot0 + f, pg);
+                double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + ci] : 1.0;
+                double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + ci] : 0.0;
+                double sv = raw * sc + sh;
+                p.E[((size_t)fr * (p.S + 1) + row) * ncols + n_res + ci] = sv;
+                v = (float)sv;
+            } else {
+                v = fmaf((float)raw, ss.x, ss.y);
+            }
         }
         return v;
     };
-    if (owner) {
-        for (int i = lane; i < 16 * kin_p; i += 64) store_in(i, load_in(0, i));
-        if (HARVEST) {
-            stage_teacher(0);
-            // E row 0 = [0, scale(u[0])]  (pyESN.py:179,189): state part; input part via row -1+1
-            for (int i = lane; i < 16 * ncols; i += 64) {
-                const int f = wave * 16 + i / ncols, c = i % ncols;
+    auto stage_inputs = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < OC; ++i) {
+            if (!own[i]) continue;
+            const int c = wave + i * NW;
+            for (int e = lane; e < 16 * kin_p; e += 64)
+                TR::store1(zt + (size_t)(c * 16 + e / kin_p) * row_bytes + (size_t)(g.kin + e % kin_p) * ES,
+                           load_in(s, c, e));
+        }
+    };
+    auto stage_teacher = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < OC; ++i) {
+            if (!own[i]) continue;
+            const int c = wave + i * NW;
+            for (int e = lane; e < 16 * kfb_p; e += 64) {
+                const int f = c * 16 + e / kfb_p, co = e % kfb_p;
                 int pg;
                 const int fr = slot_frame(p, slot0 + f, pg);
-                if (fr < 0) continue;
+                float v = 0.f;
+                if (fr >= 0 && co < n_out) {
+                    double raw = p.D[((size_t)fr * (p.S + 1) + s) * n_out + co];
+                    double sc = p.t_scale ? p.t_scale[(size_t)pg * n_out + co] : 1.0;
+                    double sh = p.t_shift ? p.t_shift[(size_t)pg * n_out + co] : 0.0;
+                    v = (float)(raw * sc + sh);
+                }
+                TR::store1(zt + (size_t)f * row_bytes + (size_t)(g.kfb + co) * ES, v);
+            }
+        }
+    };
+    stage_inputs(0);
+    if (HARVEST) {
+        stage_teacher(0);
+        // E row 0 = [0, scale(u[0])]  (pyESN.py:179,189): wave w writes frames w, w+NW, ...
+        for (int f = wave; f < BT; f += NW) {
+            int pg;
+            const int fr = slot_frame(p, slot0 + f, pg);
+            if (fr < 0) continue;
+            double* er = p.E + ((size_t)fr * (p.S + 1)) * ncols;
+            for (int c = lane; c < ncols; c += 64) {
                 double v = 0.0;
                 if (c >= n_res) {
                     const int ci = c - n_res;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + ci] : 0.0;
                     v = raw * sc + sh;
                 }
-                p.E[((size_t)fr * (p.S + 1)) * ncols + c] = v;
+                er[c] = v;
             }
         }
     }
@@ -288,22 +291,27 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     const float noise = (float)p.noise;
     const float n_c1 = noise * (1.0f / 256.0f), n_c0 = noise * (0.5f / 256.0f - 0.5f);
     const char* bbase = zt + (size_t)r * row_bytes + 16 * h;
-    const char* zrow = zt + (size_t)of * row_bytes + 16 * oq;      // owner readout B rows
-    f32x4 yacc[MAX_OT];                                              // running readout (owners)
+    // readout B rows of the owned tiles: frame c*16 + ofc, bytes 64 kk + 16 oq
+    const char* zrow0 = zt + (size_t)(wave * 16 + ofc) * row_bytes + 16 * oq;
+    const size_t zrow_step = (size_t)NW * 16 * row_bytes;
+    f32x4 yacc[OC];
 #pragma unroll
-    for (int ot = 0; ot < MAX_OT; ++ot) yacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < OC; ++i) yacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool ro_simple = (g.ro_parts == 1);
+    // (a per-tile rotation of the k walk was measured SLOWER than every CU streaming the same
+    //  weight lines at the same time: 27.9k vs 23.1k cycles in G1 -- keep it at 0)
+    constexpr int krot = 0;
 
-    // readout over 64-byte groups [k0, k1) of this owner's 16 frames, accumulating into yacc
+    // readout MFMAs over 64-byte groups [k0, k1) of the owned tiles, accumulating into yacc
     auto readout_groups = [&](int k0, int k1) {
         for (int kk = k0; kk < k1; ++kk) {
-            const u32x4 rb = *reinterpret_cast<const u32x4*>(zrow + kk * 64);
 #pragma unroll
-            for (int ot = 0; ot < MAX_OT; ++ot) {
-                if (ot < n_ot) {
+            for (int i = 0; i < OC; ++i) {
+                if (wop[i]) {
+                    const u32x4 rb = *reinterpret_cast<const u32x4*>(zrow0 + i * zrow_step + kk * 64);
                     for (int part = 0; part < g.ro_parts; ++part) {
-                        const u32x4 ra = *reinterpret_cast<const u32x4*>(
-                            wop + ((size_t)(part * n_ot + ot) * nk64 + kk) * 1024);
-                        TR::mma16(yacc[ot], ra, rb);
+                        const u32x4 ra = *reinterpret_cast<const u32x4*>(wop[i] + ((size_t)part * nk64 + kk) * 1024);
+                        TR::mma16(yacc[i], ra, rb);
                     }
                 }
             }
@@ -312,47 +320,41 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     // Y complete: feedback rows into Zt, unscaled output row `orow` to HBM, reset yacc
     auto finish_readout = [&](int orow, bool write_fb) {
 #pragma unroll
-        for (int ot = 0; ot < MAX_OT; ++ot) {
-            if (ot < n_ot) {
-                f32x4 y = yacc[ot];
-                if (g.ro_fold) {          // rows 8..15 (lanes 32..63) hold the residual image's product
+        for (int i = 0; i < OC; ++i) {
+            if (!wop[i]) continue;
+            const int c = wave + i * NW;
+            const int of = c * 16 + ofc;
+            f32x4 y = yacc[i];
+            if (g.ro_fold) {          // rows 8..15 (lanes 32..63) hold the residual image's product
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] += __shfl_xor(y[j], 32);
-                }
-                y *= wo_inv;
-                const int o0 = ot * 16 + 4 * oq;
-                if (o0 < kfb_p) {
-                    if (write_fb)
-                        TR::store4(zt + (size_t)of * row_bytes + (size_t)(g.kfb + o0) * ES, y[0], y[1], y[2], y[3]);
-                    if (orow >= 0 && ro_fr >= 0) {
-                        double* yo = p.Y + ((size_t)ro_fr * out_rows + orow) * n_out;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int o = o0 + j;
-                            if (o < n_out) yo[o] = (double)((y[j] - un_sh[j]) * un_inv[j]);
-                        }
-                    }
-                }
-                yacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) y[j] += __shfl_xor(y[j], 32);
             }
+            y *= wo_inv[i];
+            const int o0 = 4 * oq;
+            if (o0 < kfb_p) {
+                if (write_fb)
+                    TR::store4(zt + (size_t)of * row_bytes + (size_t)(g.kfb + o0) * ES, y[0], y[1], y[2], y[3]);
+                const int fr = tab_fr[of];
+                if (orow >= 0 && fr >= 0) {
+                    double* yo = p.Y + ((size_t)fr * out_rows + orow) * n_out;
+                    const float2* un = tab_un + c * 16 + o0;               // {1/scale, shift}
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (o0 + j < n_out) yo[o0 + j] = (double)((y[j] - un[j].y) * un[j].x);
+                }
+            }
+            yacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    bool any_ro = false;
+#pragma unroll
+    for (int i = 0; i < OC; ++i) any_ro = any_ro || (wop[i] != nullptr);
 
 #ifdef ESN_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     for (int s = 0; s < p.S; ++s) {
         ESN_STAMP(t0)
-        // next step's input rows: issue the HBM loads now, park them in registers
-        float in_next[NIN];
-        const bool have_next = owner && (s + 1 < p.S);
-        if (have_next && in_fits) {
-#pragma unroll
-            for (int j = 0; j < NIN; ++j) {
-                in_next[j] = HARVEST ? ((lane + 64 * j < 16 * kin_p) ? load_in(s + 1, lane + 64 * j) : 0.f)
-                                     : load_in_fast(s + 1, j);
-            }
-        }
         // ================= phase G1: state k-groups (+ readout of Y_s) ===========
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -362,53 +364,102 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-        u32x4 a_cur[MT], a_nxt[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            a_cur[mt] = *reinterpret_cast<const u32x4*>(wp + (size_t)mt * nkg * 1024);
-        auto main_groups = [&](int k0, int k1) {
-            for (int kg = k0; kg < k1; ++kg) {
-                const int kn = (kg + 1 < nkg) ? kg + 1 : kg;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    a_nxt[mt] = *reinterpret_cast<const u32x4*>(wp + ((size_t)mt * nkg + kn) * 1024);
-                u32x4 b[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    b[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + kg * 32);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) TR::mma32(acc[mt][nt], a_cur[mt], b[nt]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
-            }
+        // software pipeline: A fragments two k-groups ahead (L2 latency), B fragments one ahead (LDS)
+        u32x4 aA[MT], aB[MT], aC[MT], bA[NT], bB[NT];
+        // position i of the k sequence -> k-group: the state groups are walked from a per-tile
+        // rotation so the CUs of an XCD do not all hit the same L2 channel at the same time
+        auto kg_of = [&](int i) -> int {
+            if (i >= nkgS) return i < nkg ? i : nkg - 1;
+            int kr = (i >> 1) + krot;
+            kr = kr >= nk64S ? kr - nk64S : kr;
+            return 2 * kr + (i & 1);
         };
-        const bool ro_now = do_ro && s > 0;
-        if (ro_now) {
+        auto loadA = [&](u32x4 (&a)[MT], int pos) {
+            const int kg = kg_of(pos);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const u32x4*>(wp + ((size_t)mt * nkg + kg) * 1024);
+        };
+        auto loadB = [&](u32x4 (&b)[NT], int pos) {
+            const int kg = kg_of(pos);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + kg * 32);
+        };
+        auto mma_all = [&](const u32x4 (&b)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) TR::mma32(acc[mt][nt], aA[mt], b[nt]);
+        };
+        auto rotateA = [&]() {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { aA[mt] = aB[mt]; aB[mt] = aC[mt]; }
+        };
+        const bool ro_now = any_ro && s > 0;
+        loadA(aA, 0); loadA(aB, 1); loadB(bA, 0);
+        // Two k-groups per trip, B fragments ping-pong bA / bB; every trip is branch-free.  (The
+        // last trip prefetches the first [U|F] group early: it is re-read after the barrier.)
+        if (ro_now && ro_simple) {
+            // readout operands: W_out fragment one 64-byte group ahead, state fragment a k-group early
+            u32x4 ra_cur[OC], ra_nxt[OC], rb[OC];
+#pragma unroll
+            for (int i = 0; i < OC; ++i)
+                ra_cur[i] = wop[i] ? *reinterpret_cast<const u32x4*>(wop[i] + (size_t)krot * 1024) : u32x4{0, 0, 0, 0};
             for (int kk = 0; kk < nk64S; ++kk) {
-                main_groups(2 * kk, 2 * kk + 2);
-                readout_groups(kk, kk + 1);
+                loadA(aC, 2 * kk + 2); loadB(bB, 2 * kk + 1);
+                const int kc = kg_of(2 * kk) >> 1;                               // this trip's 64-byte group
+                const int kn = kk + 1 < nk64S ? (kg_of(2 * kk + 2) >> 1) : kc;   // next trip's
+#pragma unroll
+                for (int i = 0; i < OC; ++i) {
+                    rb[i] = *reinterpret_cast<const u32x4*>(zrow0 + i * zrow_step + kc * 64);
+                    ra_nxt[i] = wop[i] ? *reinterpret_cast<const u32x4*>(wop[i] + (size_t)kn * 1024) : u32x4{0, 0, 0, 0};
+                }
+                mma_all(bA); rotateA();
+                loadA(aC, 2 * kk + 3); loadB(bA, 2 * kk + 2);
+                mma_all(bB);
+#pragma unroll
+                for (int i = 0; i < OC; ++i) { TR::mma16(yacc[i], ra_cur[i], rb[i]); ra_cur[i] = ra_nxt[i]; }
+                rotateA();
             }
-            finish_readout(s - 1 - p.transient, true);
         } else {
-            main_groups(0, nkgS);
+            for (int kk = 0; kk < nk64S; ++kk) {
+                loadA(aC, 2 * kk + 2); loadB(bB, 2 * kk + 1);
+                mma_all(bA); rotateA();
+                loadA(aC, 2 * kk + 3); loadB(bA, 2 * kk + 2);
+                mma_all(bB); rotateA();
+                if (ro_now) { const int kc = kg_of(2 * kk) >> 1; readout_groups(kc, kc + 1); }
+            }
         }
+        if (ro_now) finish_readout(s - 1 - p.transient, true);
         ESN_STAMP(t1)
-        if (!HARVEST) __syncthreads();          // F_s visible to every wave
+        if (!HARVEST) __syncthreads();            // F_s visible to every wave
         ESN_STAMP(t2)
         // ================= phase G2: input + feedback k-groups =====================
-        main_groups(nkgS, nkg);
-        if (do_ro) readout_groups(nk64S, nk64);   // yU_s (feedback columns carry zero weights)
+        loadB(bA, nkgS);
+        for (int kg = nkgS; kg < nkg; ++kg) {
+            loadA(aC, kg + 2);
+            if (kg + 1 < nkg) loadB(bB, kg + 1);
+            mma_all(bA); rotateA();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bA[nt] = bB[nt];
+        }
+        if (any_ro) readout_groups(nk64S, nk64);  // yU_s (feedback columns carry zero weights)
         ESN_STAMP(t3)
         __syncthreads();                          // every wave has finished reading Z_s
         ESN_STAMP(t4)
 
         // ================= phase E: X_{s+1} = tanh(P) + noise =====================
+        // next step's inputs first: the HBM latency hides under the activation arithmetic
+        const bool have_next = s + 1 < p.S;
+        if (have_next) {
+            stage_inputs(s + 1);
+            if (HARVEST) stage_teacher(s + 1);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = nt * 32 + r;
-            const int fr = col_fr[nt];
+            const int fr = tab_fr[col];
             uint32_t key = 0;
             const double* nz = nullptr;
             if (NOISE == ESN_NOISE_COUNTER)
@@ -446,26 +497,13 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (have_next) {
-            if (in_fits) {
-#pragma unroll
-                for (int j = 0; j < NIN; ++j) {
-                    const int i = lane + 64 * j;
-                    if (i < 16 * kin_p) store_in(i, in_next[j]);
-                }
-            } else {
-                for (int i = lane; i < 16 * kin_p; i += 64) store_in(i, load_in(s + 1, i));
-            }
-            if (HARVEST) stage_teacher(s + 1);
-        }
         ESN_STAMP(t5)
         __syncthreads();                          // X_{s+1}, U_{s+1} (, F_{s+1}) complete
         ESN_STAMP(t6)
         if (HARVEST) {
             // E row s+1, state columns, straight from the LDS image: wave w copies frames w, w+NW, ...
             for (int f = wave; f < BT; f += NW) {
-                int pg;
-                const int fr = slot_frame(p, slot0 + f, pg);
+                const int fr = tab_fr[f];
                 if (fr < 0) continue;
                 double* er = p.E + ((size_t)fr * (p.S + 1) + (s + 1)) * ncols;
                 const char* zr = zt + (size_t)f * row_bytes;
@@ -478,7 +516,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 #endif
     }
     // final readout Y_S = yU_{S-1} + Wout_x X_S
-    if (do_ro) {
+    if (any_ro) {
         readout_groups(0, nk64S);
         finish_readout(p.S - 1 - p.transient, false);
     }
@@ -492,7 +530,8 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 
 template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE>
 static int launch_k(const RecurParams& p, hipStream_t stream) {
-    size_t lds = (size_t)p.g.Bt * p.g.Ks * TR::ES;
+    const int kin_p = p.g.kfb - p.g.kin, nown = p.g.Bt / 16;
+    size_t lds = (size_t)p.g.Bt * p.g.Ks * TR::ES + 4 * (size_t)p.g.Bt + 8 * (size_t)nown * (kin_p + 16);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
