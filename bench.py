@@ -171,6 +171,18 @@ def main():
     peak = PEAK_TFLOPS[args.precision]
     c = counters.cpu().numpy()[0]
 
+    # HBM bytes per launch of the dominant kernel from the last committed PMC pass, if it was taken
+    # on this workload (tools/pmc_traffic.py on the GPU box; FETCH_SIZE/WRITE_SIZE in their own passes)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.precision)
+    if os.path.exists(pmc_path):
+        try:
+            pj = json.load(open(pmc_path))
+            if pj.get("blocks") == G and pj.get("traffic_bytes_per_launch"):
+                traffic = pj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
     if rank == 0:
         out = {
             "metric": "OFDM symbols/s through the ESN detector (4x8 TDL-B, N=128, N_res=%d; train+predict+detect)" % args.n_res,
@@ -193,7 +205,9 @@ def main():
             "predict_kernel_ms": kernel_ms,
             "predict_only_symbols_per_s": world * frames_per_step / (kernel_ms * 1e-3),
             "roofline": {"bound": "mfma", "kernel": "esn::recur_mfma_kernel (predict)", "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic_*.json)",
+                         "algorithmic_bytes_per_launch": frames_per_step * 8 * (params.t_frame * sweep.n_in + params.n_sub * sweep.n_out),
                          "flop_per_frame": flop_per_frame(args.n_res, sweep.n_in, sweep.n_out, T),
                          "frames_per_launch": frames_per_step},
             "device": _lib.device_info(),

@@ -51,7 +51,8 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
     g->ro_fold = (es == 2 && n_out <= 8) ? 1 : 0;
     g->ro_parts = (es == 2 && !g->ro_fold) ? 2 : 1;
     // Zt image + the small frame / scale tables behind it (esn_recur_mfma_impl.h)
-    const size_t tables = 4 * (size_t)g->Bt + 8 * (size_t)(g->Bt / 16) * ((g->kfb - g->kin) + 16);
+    const size_t tables = 4 * (size_t)g->Bt + 8 * (size_t)(g->Bt / 16) * ((g->kfb - g->kin) + 16)
+                          + 8 * (size_t)g->Bt * n_in;     // + raw input rows of the next step (LDS-DMA)
     return (size_t)g->Bt * g->Ks * es + tables <= 160 * 1024;
 }
 

@@ -9,7 +9,7 @@ int launch_recur_mfma_f16(const RecurParams& p, hipStream_t stream) {
     ESN_CASE(4, 1, 2)
     ESN_CASE(8, 1, 4)
     ESN_CASE(8, 2, 4)
-    ESN_CASE(4, 4, 4)
+    ESN_CASE(8, 2, 3)
     ESN_CASE(8, 4, 2)
     ESN_CASE(16, 4, 1)
     ESN_CASE(8, 2, 1)

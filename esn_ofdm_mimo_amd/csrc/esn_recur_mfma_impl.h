@@ -150,6 +150,8 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     int* tab_fr = reinterpret_cast<int*>(zt + (size_t)BT * row_bytes);
     float2* tab_in = reinterpret_cast<float2*>(tab_fr + BT);
     float2* tab_un = tab_in + NOWN * kin_p;
+    // raw float64 input rows of the NEXT step, filled by LDS-DMA (no VGPRs): [NOWN][16][n_in]
+    double* in_raw = reinterpret_cast<double*>(tab_un + NOWN * 16);
     for (int i = tid; i < BT; i += NTHREADS) { int gtmp; tab_fr[i] = slot_frame(p, slot0 + i, gtmp); }
     for (int i = tid; i < NOWN * kin_p; i += NTHREADS) {
         const int c16 = i / kin_p, c = i % kin_p;
@@ -264,6 +266,49 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             }
         }
     };
+    // LDS-DMA path for the per-step inputs (predict): every 16-byte chunk of the owned frames' input
+    // row goes global -> LDS with no register staging; the owner wave converts it in phase E.
+    const int cpf = n_in / 2;                                   // 16-byte chunks per frame row
+    const bool in_dma = !HARVEST && (n_in % 2 == 0) && ((size_t)p.T_in * n_in % 2 == 0);
+    auto dma_inputs = [&](int s) {
+        const int row = s + p.in_row_off;
+#pragma unroll
+        for (int i = 0; i < OC; ++i) {
+            if (!own[i]) continue;
+            const int c = wave + i * NW;
+            for (int e0 = 0; e0 < 16 * cpf; e0 += 64) {          // wave-uniform trip count
+                const int e = e0 + lane;
+                const int f = e / cpf, ch = e % cpf;
+                const int fr = (e < 16 * cpf) ? tab_fr[c * 16 + f] : -1;
+                if (fr >= 0 && row < p.T_in) {
+                    const double* src = p.U + (size_t)fr * in_stride + (size_t)row * n_in + 2 * ch;
+                    // destination = wave-uniform base + lane*16 (hardware): chunk e of this tile
+                    char* dst = reinterpret_cast<char*>(in_raw + (size_t)c * 16 * n_in) + (size_t)e0 * 16;
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)src,
+                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+            }
+        }
+    };
+    auto commit_inputs = [&](int s) {                             // after the issuing wave's vmcnt(0)
+        const int row = s + p.in_row_off;
+#pragma unroll
+        for (int i = 0; i < OC; ++i) {
+            if (!own[i]) continue;
+            const int c = wave + i * NW;
+            for (int e = lane; e < 16 * kin_p; e += 64) {
+                const int f = e / kin_p, ci = e % kin_p;
+                float v = 0.f;
+                if (tab_fr[c * 16 + f] >= 0 && ci < n_in) {
+                    const float2 ss = tab_in[c * kin_p + ci];
+                    const double raw = (row < p.T_in) ? in_raw[((size_t)c * 16 + f) * n_in + ci] : 0.0;
+                    v = fmaf((float)raw, ss.x, ss.y);
+                }
+                TR::store1(zt + (size_t)(c * 16 + f) * row_bytes + (size_t)(g.kin + ci) * ES, v);
+            }
+        }
+    };
     stage_inputs(0);
     if (HARVEST) {
         stage_teacher(0);
@@ -355,6 +400,8 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 #endif
     for (int s = 0; s < p.S; ++s) {
         ESN_STAMP(t0)
+        const bool have_next = s + 1 < p.S;
+        if (in_dma && have_next) dma_inputs(s + 1);          // lands in in_raw while the GEMM runs
         // ================= phase G1: state k-groups (+ readout of Y_s) ===========
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -451,9 +498,13 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 
         // ================= phase E: X_{s+1} = tanh(P) + noise =====================
         // next step's inputs first: the HBM latency hides under the activation arithmetic
-        const bool have_next = s + 1 < p.S;
         if (have_next) {
-            stage_inputs(s + 1);
+            if (in_dma) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own DMA (issued a GEMM ago)
+                commit_inputs(s + 1);
+            } else {
+                stage_inputs(s + 1);
+            }
             if (HARVEST) stage_teacher(s + 1);
         }
 #pragma unroll
@@ -531,7 +582,8 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE>
 static int launch_k(const RecurParams& p, hipStream_t stream) {
     const int kin_p = p.g.kfb - p.g.kin, nown = p.g.Bt / 16;
-    size_t lds = (size_t)p.g.Bt * p.g.Ks * TR::ES + 4 * (size_t)p.g.Bt + 8 * (size_t)nown * (kin_p + 16);
+    size_t lds = (size_t)p.g.Bt * p.g.Ks * TR::ES + 4 * (size_t)p.g.Bt + 8 * (size_t)nown * (kin_p + 16)
+                 + 8 * (size_t)p.g.Bt * p.n_in;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
