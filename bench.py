@@ -82,7 +82,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="f16", choices=["f32", "f16", "bf16", "f64"])
-    ap.add_argument("--fit-precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--fit-precision", default="auto", choices=["auto", "f16", "bf16", "f32", "f64"],
+                    help="harvest arithmetic; auto = the predict precision for f16/bf16 (states are then rounded\n"
+                         "the same way at train and detect time), f32 otherwise")
     ap.add_argument("--n-res", type=int, default=512)
     ap.add_argument("--blocks", type=int, default=0, help="coherence blocks per rank per step (0 = auto)")
     ap.add_argument("--frames-per-block", type=int, default=0, help="0 = L of the reference (75 at N=128)")
@@ -109,6 +111,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.fit_precision == "auto":
+        args.fit_precision = args.precision if args.precision in ("f16", "bf16") else "f32"
     params = LinkParams()                               # 4x8 TDL-B, N=128, 16-QAM
     F = args.frames_per_block or params.coherence_symbols
     tile = {"f32": 64, "f16": 128, "bf16": 128, "f64": 8}[args.precision]

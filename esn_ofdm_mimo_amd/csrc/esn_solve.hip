@@ -7,6 +7,7 @@
 //
 // The working matrix is column-major in the caller's workspace (L2 resident);
 // reflector j is applied to the trailing columns one wave per column.
+#include <stdlib.h>
 #include "esn_common.h"
 
 namespace esn {
@@ -18,6 +19,7 @@ struct SolveParams {
     double* W_out; int* status;
     double* work; size_t work_stride;   // doubles per group
     int m, n, wide;
+    int skip;   // diagnostic only (ESN_CHOL_SKIP env): bit0 Gram, bit1 Cholesky, bit2 solves, bit3 W_out
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -246,21 +248,41 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     // tall case also needs A^T B: thread (o, i) partial sums, o < nrhs, i < n  -> first nrhs*128 threads
     double atb = 0.0;
     const int ao = tid / CH_NP, ai = tid % CH_NP;
-    for (int k0 = 0; k0 < m; k0 += CH_KC) {
-        __syncthreads();
-        // stage As[kk][i] = a(i, k0+kk);  wide: A[i][k], tall: A[k][i]
-        for (int e = tid; e < CH_KC * CH_NP; e += 1024) {
+    // chunk staging is register-prefetched one chunk ahead and double-buffered in LDS, so the
+    // global-load latency of chunk c+1 hides under the FMAs of chunk c (one barrier per chunk)
+    constexpr int EPT = CH_KC * CH_NP / 1024;          // staged elements per thread (4)
+    double stg[EPT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + 1024 * q;
             int kk, i;
             if (wide) { i = e / CH_KC; kk = e % CH_KC; } else { kk = e / CH_NP; i = e % CH_NP; }
             const int k = k0 + kk;
-            double v = 0.0;
-            if (i < n && k < m) v = wide ? A[(size_t)i * cols + k] : A[(size_t)k * cols + i];
-            As[kk * AS_LD + i] = v;
+            stg[q] = (i < n && k < m) ? (wide ? A[(size_t)i * cols + k] : A[(size_t)k * cols + i]) : 0.0;
         }
-        __syncthreads();
+    };
+    auto commit = [&](double* dst) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = tid + 1024 * q;
+            int kk, i;
+            if (wide) { i = e / CH_KC; kk = e % CH_KC; } else { kk = e / CH_NP; i = e % CH_NP; }
+            dst[kk * AS_LD + i] = stg[q];
+        }
+    };
+    double* Abuf[2] = {As, As + CH_KC * AS_LD};
+    fetch(0);
+    commit(Abuf[0]);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < ((sp.skip & 1) ? CH_KC : m); k0 += CH_KC) {
+        const bool more = k0 + CH_KC < m;
+        if (more) fetch(k0 + CH_KC);
+        const double* Ac = Abuf[cur];
         const int kmax = (m - k0 < CH_KC) ? m - k0 : CH_KC;
         for (int kk = 0; kk < kmax; ++kk) {
-            const double* row = As + kk * AS_LD;
+            const double* row = Ac + kk * AS_LD;
             double a0 = row[4 * ty], a1 = row[4 * ty + 1], a2 = row[4 * ty + 2], a3 = row[4 * ty + 3];
             double b0 = row[4 * tx], b1 = row[4 * tx + 1], b2 = row[4 * tx + 2], b3 = row[4 * tx + 3];
             acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
@@ -276,8 +298,11 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
             const double sc = sp.t_scale ? sp.t_scale[(size_t)g * nrhs + ao] : 1.0;
             const double sh = sp.t_shift ? sp.t_shift[(size_t)g * nrhs + ao] : 0.0;
             for (int kk = 0; kk < kmax; ++kk)
-                atb = fma(As[kk * AS_LD + ai], Dg[(size_t)(k0 + kk) * nrhs + ao] * sc + sh, atb);
+                atb = fma(Ac[kk * AS_LD + ai], Dg[(size_t)(k0 + kk) * nrhs + ao] * sc + sh, atb);
         }
+        if (more) commit(Abuf[cur ^ 1]);
+        __syncthreads();
+        cur ^= 1;
     }
     __syncthreads();
     // ---- phase 2: G and the right-hand sides into LDS ----------------------------------
@@ -310,7 +335,7 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
 
     // ---- phase 3: left-looking Cholesky, 8 threads per row, one column per iteration ----
     const int ri = tid >> 3, part = tid & 7;         // row 0..127
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < ((sp.skip & 2) ? 1 : n); ++j) {
         double s = 0.0;
         if (ri >= j && ri < n) {
             const double* Li = Gs + ri * CH_LD;
@@ -334,7 +359,7 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     }
 
     // ---- phase 4: L L^T x = b, one wave per right-hand side ------------------------------
-    for (int o = wv; o < nrhs; o += 16) {
+    for (int o = wv; o < ((sp.skip & 4) ? 0 : nrhs); o += 16) {
         double* x = Bs + o * CH_NP;
         for (int j = 0; j < n; ++j) {
             const double* Lj = Gs + j * CH_LD;
@@ -359,7 +384,7 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     // ---- phase 5: W_out ---------------------------------------------------------------------
     if (wide) {
         // W_out[o][c] = sum_i A[i][c] alpha[i][o]
-        for (int e = tid; e < nrhs * cols; e += 1024) {
+        for (int e = tid; e < ((sp.skip & 8) ? 0 : nrhs * cols); e += 1024) {
             const int o = e / cols, c = e % cols;
             const double* al = Bs + o * CH_NP;
             double a = 0.0;
@@ -386,6 +411,7 @@ int launch_readout_chol(const double* E, const double* D, int n_groups, int T, i
     sp.cols = cols; sp.n_out = n_out; sp.t_scale = t_scale; sp.t_shift = t_shift;
     sp.W_out = W_out; sp.status = status; sp.work = nullptr; sp.work_stride = 0;
     sp.wide = rows < cols; sp.m = sp.wide ? cols : rows; sp.n = n;
+    { const char* sk = getenv("ESN_CHOL_SKIP"); sp.skip = sk ? atoi(sk) : 0; }
     const size_t lds = sizeof(double) * ((size_t)CH_NP * CH_LD + (size_t)n_out * CH_NP);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(readout_chol_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
