@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--frames-per-block", type=int, default=0, help="0 = L of the reference (75 at N=128)")
     ap.add_argument("--ebno", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-blocks", type=int, default=4)
+    ap.add_argument("--cpu-blocks", type=int, default=32, help="cpu_baseline sample: blocks of L frames (~10-15 s)")
     ap.add_argument("--predict-only", action="store_true", help="time the predict+detect leg only")
     ap.add_argument("--solve", default="auto", choices=["auto", "qr", "chol"])
     args = ap.parse_args()
@@ -119,7 +119,8 @@ def main():
     # auto: a whole number of workgroup tiles per CU (tiles = G * ceil16(F) / tile), ~5-10 rounds
     fpad = ((F + 15) // 16) * 16
     G = args.blocks or max(1, (5 * 256 * 128) // fpad)
-    sweep = DetectorSweep(params, n_reservoir=args.n_res, noise=0.001, seed=1234 + rank,
+    sweep = DetectorSweep(params, n_reservoir=args.n_res, noise=0.001, seed=1234,   # same reservoir on every rank
+                         
                           precision=args.precision, fit_precision=args.fit_precision,
                           reservoirs="shared", rank=rank, world_size=world, solve_method=args.solve)
     data = sweep.src.blocks_fast(args.ebno, 0, rank * G, G, F)

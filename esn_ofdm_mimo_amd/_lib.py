@@ -42,6 +42,10 @@ SIGNATURES = {
                                           _dp, _dp, _dp, _ip, _vp, _vp]),
     "esn_readout_solve_chol_batch": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                _dp, _dp, _dp, _ip, _vp]),
+    "esn_gen_taps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _dp,
+                               C.c_uint64, C.c_uint64, _dp, _vp]),
+    "esn_gen_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 _dp, _dp, C.c_double, _dp, _vp, _dp, C.c_uint64, C.c_uint64, _vp, _dp, _dp, _vp]),
     "esn_detect_count": (C.c_int, [_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _vp,
                                    _vp, _vp, _dp, _vp]),
 }

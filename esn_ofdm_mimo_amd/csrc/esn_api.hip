@@ -3,6 +3,7 @@
 // the thread-local error string -- every call is capturable into a hipGraph.
 #include <stdarg.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 #include "esn_common.h"
 
@@ -28,6 +29,9 @@ int launch_readout_solve(const double* E, const double* D, int n_groups, int T, 
 int launch_readout_chol(const double* E, const double* D, int n_groups, int T, int transient,
                         int cols, int n_out, const double* t_scale, const double* t_shift,
                         double* W_out, int* status, hipStream_t stream);
+// esn_gen.hip
+int launch_gen_taps(const TapParams& tp, hipStream_t stream);
+int launch_gen_frames(const FrameGenParams& fp, hipStream_t stream);
 // esn_detect.hip
 int launch_detect_count(const DetectParams& dp, hipStream_t stream);
 }  // namespace esn
@@ -255,6 +259,66 @@ int esn_detect_count(const double* Y, int n_frames, int frames_per_group, int n_
     dp.log2n = log2n; dp.n_t = n_t; dp.m = bits_per_sym; dp.p_i = p_i; dp.tx_bits = tx_bits;
     dp.err = err_count; dp.bits = bit_count; dp.X_hat = X_hat;
     return hip_fail(launch_detect_count(dp, (hipStream_t)stream), "esn_detect_count");
+}
+
+static const double kTdlbDelay[23] = {0.0000, 0.1072, 0.2155, 0.2095, 0.2870, 0.2986, 0.3752, 0.5055, 0.3681,
+                                      0.3697, 0.5700, 0.5283, 1.1021, 1.2756, 1.5474, 1.7842, 2.0169, 2.8294,
+                                      3.0219, 3.6187, 4.1067, 4.2790, 4.7834};
+static const double kTdlbPowDb[23] = {0.0, -2.2, -4.0, -3.2, -9.8, -1.2, -3.4, -5.2, -7.6, -3.0, -8.9, -9.0,
+                                      -4.8, -5.7, -7.5, -1.9, -7.6, -12.2, -9.8, -11.4, -14.9, -9.2, -11.3};
+
+int esn_gen_taps(int kind, int n_blocks, int n_r, int n_t, int isi, double fs_hz, double ds_ns,
+                 const double* gains_in, uint64_t seed, uint64_t link_offset, double* taps, void* stream) {
+    if (!taps) return fail(-1, "esn_gen_taps: null pointer");
+    if (kind < 0 || kind > 2 || n_blocks <= 0 || n_r <= 0 || n_t <= 0 || isi <= 0 || isi > 16)
+        return fail(-1, "esn_gen_taps: invalid arguments (kind=%d isi=%d)", kind, isi);
+    TapParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.kind = kind; tp.n_links = n_blocks * n_r * n_t; tp.isi = isi;
+    if (kind == 0) {
+        tp.n_paths = 23;
+        double sum = 0.0;
+        for (int i = 0; i < 23; ++i) sum += pow(10.0, kTdlbPowDb[i] / 10.0);
+        for (int i = 0; i < 23; ++i) {
+            tp.path_sqrt_pow[i] = sqrt(pow(10.0, kTdlbPowDb[i] / 10.0) / sum);
+            tp.path_delay_samples[i] = kTdlbDelay[i] * ds_ns * 1e-9 * fs_hz;
+        }
+    } else if (kind == 1) {
+        tp.n_paths = isi;
+        const int cp = isi - 1;
+        const double tc = (cp / 9.0 > 1e-12) ? cp / 9.0 : 1e-12;
+        double sum = 0.0;
+        for (int i = 0; i < isi; ++i) sum += exp(-(double)i / tc);
+        for (int i = 0; i < isi; ++i) tp.path_sqrt_pow[i] = sqrt(exp(-(double)i / tc) / sum);
+    } else {
+        tp.n_paths = 1;
+        tp.path_sqrt_pow[0] = 1.0;
+    }
+    tp.gains_in = gains_in; tp.seed = seed; tp.link_offset = link_offset; tp.taps = taps;
+    return hip_fail(launch_gen_taps(tp, (hipStream_t)stream), "esn_gen_taps");
+}
+
+int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_t, int n_r, int isi,
+                   int bits_per_sym, const double* p_i, const double* a_clip, double no, const double* taps,
+                   const uint8_t* bits_in, const double* noise_in, uint64_t seed, uint64_t frame_offset,
+                   uint8_t* bits, double* x_cp, double* y_cp, void* stream) {
+    if (!p_i || !a_clip || !taps || !bits || !y_cp) return fail(-1, "esn_gen_frames: null pointer");
+    int log2n = 0;
+    while ((1 << log2n) < n_sub) ++log2n;
+    if ((1 << log2n) != n_sub || n_sub < 2 || n_sub > 2048)
+        return fail(-1, "esn_gen_frames: N=%d must be a power of two in [2, 2048]", n_sub);
+    if (bits_per_sym < 2 || bits_per_sym > 10 || (bits_per_sym & 1))
+        return fail(-1, "esn_gen_frames: bits_per_sym=%d must be even (square QAM)", bits_per_sym);
+    if (n_frames <= 0 || frames_per_block <= 0 || cp < 0 || cp >= n_sub || n_t <= 0 || n_r <= 0 || isi <= 0)
+        return fail(-1, "esn_gen_frames: invalid sizes");
+    FrameGenParams fp;
+    fp.n_frames = n_frames; fp.frames_per_block = frames_per_block; fp.n_sub = n_sub; fp.log2n = log2n;
+    fp.cp = cp; fp.n_t = n_t; fp.n_r = n_r; fp.isi = isi; fp.m = bits_per_sym;
+    fp.p_i = p_i; fp.a_clip = a_clip; fp.no = no; fp.taps = taps; fp.bits_in = bits_in; fp.noise_in = noise_in;
+    fp.seed = seed; fp.frame_offset = frame_offset; fp.bits = bits; fp.x_cp = x_cp; fp.y_cp = y_cp;
+    int e = launch_gen_frames(fp, (hipStream_t)stream);
+    if (e == -1) return fail(-2, "esn_gen_frames: frame does not fit LDS");
+    return hip_fail(e, "esn_gen_frames");
 }
 
 }  // extern "C"

@@ -59,6 +59,33 @@ struct DetectParams {
     long long* err; long long* bits; double* X_hat;
 };
 
+// frame generator (esn_gen.hip)
+struct TapParams {
+    int kind;            // 0 = TDL-B, 1 = exponential PDP, 2 = flat unit-modulus (AWGN driver)
+    int n_links;         // n_blocks * n_r * n_t
+    int isi;
+    int n_paths;         // 23 for TDL-B, isi for the exponential PDP, 1 for flat
+    double path_sqrt_pow[24];        // sqrt of the (normalised) linear power of each path / tap
+    double path_delay_samples[24];   // TDL-B: normalised delay * DS * fs
+    const double* gains_in;          // optional complex [n_links][n_paths] standard normals (parity)
+    uint64_t seed; uint64_t link_offset;
+    double* taps;        // complex [n_links][isi]
+};
+
+struct FrameGenParams {
+    int n_frames, frames_per_block, n_sub, log2n, cp, n_t, n_r, isi, m;
+    const double* p_i;        // [n_blocks]  Pi = 10^(EbNo/10) No
+    const double* a_clip;     // [n_blocks]  PA clip level
+    double no;
+    const double* taps;       // complex [n_blocks][n_r][n_t][isi]
+    const uint8_t* bits_in;   // optional [B][N*m][n_t]
+    const double* noise_in;   // optional complex [B][T][n_r], unit-variance real and imaginary parts
+    uint64_t seed; uint64_t frame_offset;
+    uint8_t* bits;            // [B][N*m][n_t]
+    double* x_cp;             // optional complex [B][T][n_t] (pre-PA: the ESN teacher)
+    double* y_cp;             // complex [B][T][n_r]
+};
+
 // slot -> frame index (or -1 for padding) and its group
 __device__ __forceinline__ int slot_frame(const RecurParams& p, int slot, int& grp) {
     grp = slot / p.Fpad;

@@ -1,0 +1,210 @@
+// On-device Monte-Carlo frame generator: the producer directly upstream of the
+// detector.  float64 / complex128 like the reference; random streams are counter based
+// (Philox4x32-10 keyed by seed, counter = (frame or link index, purpose, position)), so a frame is
+// the same on any rank and any launch shape.  Every random input can also be supplied by the
+// caller (bits_in / noise_in / gains_in): that is the deterministic parity mode the tests use
+// against oracle/ofdm_frames.py.
+//
+//   gen_taps_kernel    TDL-B impulse responses   Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:127-177
+//                      exponential-PDP Rayleigh  OFDM_MIMO_2-2_NBF_LDPC.py:162-164,272-279
+//   gen_frames_kernel  bits -> QAM (:406-411) -> N*ifft (:416) -> CP (:417) -> sqrt(Pi) -> PA (:419)
+//                      -> per-link FIR, zero initial state (:422-425) -> AWGN (:426)
+#include "esn_common.h"
+
+namespace esn {
+
+struct Philox {
+    uint32_t k0, k1;
+    __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t ka, uint32_t kb) const {
+        const uint64_t p0 = (uint64_t)0xD2511F53U * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57U * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ ka;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ kb;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+    }
+    __device__ __forceinline__ void operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t (&out)[4]) const {
+        uint32_t c[4] = {c0, c1, c2, c3};
+        uint32_t ka = k0, kb = k1;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { round(c, ka, kb); ka += 0x9E3779B9U; kb += 0xBB67AE85U; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = c[i];
+    }
+};
+
+// two independent N(0,1) from two 32-bit words (Box-Muller, float64)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, double& z0, double& z1) {
+    const double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0);
+    const double u2 = ((double)b + 0.5) * (1.0 / 4294967296.0);
+    const double rr = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    z0 = rr * cs; z1 = rr * sn;
+}
+
+enum { PURPOSE_BITS = 1, PURPOSE_NOISE = 2, PURPOSE_TAPS = 3 };
+
+__global__ void gen_taps_kernel(TapParams tp) {
+    const int link = blockIdx.x * blockDim.x + threadIdx.x;
+    if (link >= tp.n_links) return;
+    const Philox ph{(uint32_t)tp.seed, (uint32_t)(tp.seed >> 32)};
+    const uint64_t gl = tp.link_offset + link;
+    double hr[16], hi[16];
+    for (int k = 0; k < tp.isi; ++k) { hr[k] = 0.0; hi[k] = 0.0; }
+    const int np = (tp.kind == 2) ? 1 : tp.n_paths;
+    for (int pth = 0; pth < np; ++pth) {
+        double gr, gi;
+        if (tp.gains_in) {
+            gr = tp.gains_in[((size_t)link * tp.n_paths + pth) * 2];
+            gi = tp.gains_in[((size_t)link * tp.n_paths + pth) * 2 + 1];
+        } else {
+            uint32_t w[4];
+            ph((uint32_t)gl, (uint32_t)(gl >> 32), PURPOSE_TAPS, (uint32_t)pth, w);
+            box_muller(w[0], w[1], gr, gi);
+        }
+        if (tp.kind == 0) {          // CN(0, p) path gain split between floor / ceil taps
+            const double a = 0.70710678118654752 * tp.path_sqrt_pow[pth];
+            gr *= a; gi *= a;
+            const double d = tp.path_delay_samples[pth];           // delay in samples
+            const int i0 = (int)floor(d);
+            const double frac = d - (double)i0;
+            if (i0 >= 0 && i0 < tp.isi) { hr[i0] = fma(gr, 1.0 - frac, hr[i0]); hi[i0] = fma(gi, 1.0 - frac, hi[i0]); }
+            if (i0 + 1 >= 0 && i0 + 1 < tp.isi) { hr[i0 + 1] = fma(gr, frac, hr[i0 + 1]); hi[i0 + 1] = fma(gi, frac, hi[i0 + 1]); }
+        } else if (tp.kind == 1) {   // one CN(0, pdp_k) tap per path
+            hr[pth] = gr * 0.70710678118654752 * tp.path_sqrt_pow[pth];
+            hi[pth] = gi * 0.70710678118654752 * tp.path_sqrt_pow[pth];
+        } else {                     // flat channel, random phase, unit modulus
+            const double a = sqrt(gr * gr + gi * gi);
+            hr[0] = a > 0 ? gr / a : 1.0; hi[0] = a > 0 ? gi / a : 0.0;
+        }
+    }
+    if (tp.kind == 0) {              // unit energy per link (driver :162-164)
+        double e = 0.0;
+        for (int k = 0; k < tp.isi; ++k) e += hr[k] * hr[k] + hi[k] * hi[k];
+        if (e > 0.0) { const double s = 1.0 / sqrt(e); for (int k = 0; k < tp.isi; ++k) { hr[k] *= s; hi[k] *= s; } }
+    }
+    for (int k = 0; k < tp.isi; ++k) {
+        tp.taps[((size_t)link * tp.isi + k) * 2] = hr[k];
+        tp.taps[((size_t)link * tp.isi + k) * 2 + 1] = hi[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int N = fp.n_sub, T = N + fp.cp, n_t = fp.n_t, n_r = fp.n_r, isi = fp.isi, m = fp.m;
+    double2* X = reinterpret_cast<double2*>(gsm);            // [n_t][N]   freq -> time (in place)
+    double2* xpa = X + (size_t)n_t * N;                       // [n_t][T]   post-PA time signal
+    double2* ctap = xpa + (size_t)n_t * T;                    // [n_r][n_t][isi]
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int frame = blockIdx.x;
+    const int blk = frame / fp.frames_per_block;
+    const uint64_t gf = fp.frame_offset + frame;
+    const Philox ph{(uint32_t)fp.seed, (uint32_t)(fp.seed >> 32)};
+    const int side = 1 << (m / 2);
+    const double norm = sqrt(2.0 * (double)(side * side - 1) / 3.0);
+
+    for (int i = tid; i < n_r * n_t * isi; i += nth)
+        ctap[i] = make_double2(fp.taps[((size_t)blk * n_r * n_t * isi + i) * 2],
+                               fp.taps[((size_t)blk * n_r * n_t * isi + i) * 2 + 1]);
+    // ---- bits -> constellation point (index = sum_b bit_b 2^b = i*side + j; Re = pam[i], Im = pam[j])
+    for (int e = tid; e < N * n_t; e += nth) {
+        const int sc = e / n_t, tx = e % n_t;
+        uint32_t idx = 0;
+        if (fp.bits_in) {
+            for (int b = 0; b < m; ++b)
+                idx |= (uint32_t)(fp.bits_in[((size_t)frame * N * m + (size_t)sc * m + b) * n_t + tx] & 1) << b;
+        } else {
+            uint32_t w[4];
+            ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_BITS, (uint32_t)e, w);
+            idx = w[0] & ((1u << m) - 1);
+        }
+        for (int b = 0; b < m; ++b)
+            fp.bits[((size_t)frame * N * m + (size_t)sc * m + b) * n_t + tx] = (uint8_t)((idx >> b) & 1);
+        const int pi_ = (int)(idx / side), pj = (int)(idx % side);
+        const int rv = (int)(__brev((unsigned)sc) >> (32 - fp.log2n));
+        X[(size_t)tx * N + rv] = make_double2((2.0 * pi_ - (side - 1)) / norm, (2.0 * pj - (side - 1)) / norm);
+    }
+    __syncthreads();
+    // ---- x = N * ifft(X): un-normalised inverse DFT, radix-2 DIT on bit-reversed input, per tx
+    const int half = N >> 1;
+    for (int s = 1; s <= fp.log2n; ++s) {
+        const int hm = 1 << (s - 1);
+        for (int e = tid; e < n_t * half; e += nth) {
+            const int tx = e / half, b = e % half;
+            const int j = b & (hm - 1);
+            const int base = ((b >> (s - 1)) << s) + j;
+            double sn, cs;
+            sincospi((double)j / (double)hm, &sn, &cs);      // w = exp(+2 pi i j / 2^s)
+            double2* xx = X + (size_t)tx * N;
+            const double2 a = xx[base], c = xx[base + hm];
+            const double tr = c.x * cs - c.y * sn, ti = c.x * sn + c.y * cs;
+            xx[base] = make_double2(a.x + tr, a.y + ti);
+            xx[base + hm] = make_double2(a.x - tr, a.y - ti);
+        }
+        __syncthreads();
+    }
+    // ---- cyclic prefix, power scaling, PA
+    const double sp = sqrt(fp.p_i[blk]), aclip = fp.a_clip[blk];
+    for (int e = tid; e < T * n_t; e += nth) {
+        const int t = e / n_t, tx = e % n_t;
+        const int n = (t < fp.cp) ? (N - fp.cp + t) : (t - fp.cp);
+        const double2 v = X[(size_t)tx * N + n];
+        const double xr = v.x * sp, xi = v.y * sp;
+        if (fp.x_cp) {
+            fp.x_cp[((size_t)frame * T + t) * n_t * 2 + 2 * tx] = xr;
+            fp.x_cp[((size_t)frame * T + t) * n_t * 2 + 2 * tx + 1] = xi;
+        }
+        const double mag = sqrt(xr * xr + xi * xi) / aclip;
+        const double gpa = 1.0 / sqrt(1.0 + mag * mag);
+        xpa[(size_t)tx * T + t] = make_double2(xr * gpa, xi * gpa);
+    }
+    __syncthreads();
+    // ---- y[t][rx] = sum_tx sum_k c[rx][tx][k] x_pa[t-k][tx] + sqrt(T No / 2) (n_re + j n_im)
+    const double sig = sqrt((double)T * fp.no * 0.5);
+    for (int e = tid; e < T * n_r; e += nth) {
+        const int t = e / n_r, rx = e % n_r;
+        double yr = 0.0, yi = 0.0;
+        for (int tx = 0; tx < n_t; ++tx) {
+            const double2* c = ctap + ((size_t)rx * n_t + tx) * isi;
+            const double2* xs = xpa + (size_t)tx * T;
+            const int kmax = t < isi - 1 ? t : isi - 1;
+            for (int k = 0; k <= kmax; ++k) {
+                const double2 cv = c[k], xv = xs[t - k];
+                yr += cv.x * xv.x - cv.y * xv.y;
+                yi += cv.x * xv.y + cv.y * xv.x;
+            }
+        }
+        double nr, ni;
+        if (fp.noise_in) {
+            nr = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rx];
+            ni = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rx + 1];
+        } else {
+            uint32_t w[4];
+            ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_NOISE, (uint32_t)e, w);
+            box_muller(w[0], w[1], nr, ni);
+        }
+        fp.y_cp[((size_t)frame * T + t) * n_r * 2 + 2 * rx] = yr + sig * nr;
+        fp.y_cp[((size_t)frame * T + t) * n_r * 2 + 2 * rx + 1] = yi + sig * ni;
+    }
+}
+
+int launch_gen_taps(const TapParams& tp, hipStream_t stream) {
+    const int threads = 128;
+    hipLaunchKernelGGL(gen_taps_kernel, dim3((tp.n_links + threads - 1) / threads), dim3(threads), 0, stream, tp);
+    return (int)hipGetLastError();
+}
+
+int launch_gen_frames(const FrameGenParams& fp, hipStream_t stream) {
+    const int T = fp.n_sub + fp.cp;
+    const size_t lds = sizeof(double2) * ((size_t)fp.n_t * fp.n_sub + (size_t)fp.n_t * T +
+                                          (size_t)fp.n_r * fp.n_t * fp.isi);
+    if (lds > 150 * 1024) return -1;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gen_frames_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gen_frames_kernel, dim3(fp.n_frames), dim3(256), lds, stream, fp);
+    return (int)hipGetLastError();
+}
+
+}  // namespace esn

@@ -5,10 +5,9 @@
                     (Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:182-238, :285-288)
     FrameSource     bits -> QAM -> N*ifft -> CP -> sqrt(Pi) -> PA -> per-link 8-tap FIR -> AWGN
                     (:323-356 pilot, :397-427 data), TDL-B taps (:127-177) or the exponential-PDP
-                    Rayleigh taps of OFDM_MIMO_2-2_NBF_LDPC.py:162-164,272-279.  Round 1 builds the
-                    frames with torch tensor ops on the device (a stand-in: the generator is row f-1
-                    of the scope table, next to move into HIP kernels); every random stream is keyed
-                    by (seed, snr index, block index), so a block is identical on any rank.
+                    Rayleigh taps of OFDM_MIMO_2-2_NBF_LDPC.py:162-164,272-279: HIP kernels
+                    (esn_gen_taps / esn_gen_frames, csrc/esn_gen.hip) with Philox counter streams keyed
+                    by (seed, snr index, global block / frame index), so a block is identical on any rank.
     DetectorSweep   per SNR point: G coherence blocks at a time -> one harvest + one solve launch
                     (training, helper_mimo_esn_generic.py:58-86), one predict launch over G*L data
                     frames, one fused detect/count launch; int64 counters [n_snr, {err, bits}]
@@ -27,13 +26,7 @@ import numpy as np
 
 from . import _lib
 from .batched import ReservoirBank
-
-TDLB_NORM_DELAYS = (0.0000, 0.1072, 0.2155, 0.2095, 0.2870, 0.2986, 0.3752, 0.5055, 0.3681,
-                    0.3697, 0.5700, 0.5283, 1.1021, 1.2756, 1.5474, 1.7842, 2.0169, 2.8294,
-                    3.0219, 3.6187, 4.1067, 4.2790, 4.7834)
-TDLB_POW_DB = (0.0, -2.2, -4.0, -3.2, -9.8, -1.2, -3.4, -5.2, -7.6, -3.0, -8.9, -9.0,
-               -4.8, -5.7, -7.5, -1.9, -7.6, -12.2, -9.8, -11.4, -14.9, -9.2, -11.3)
-
+from ._lib import check, ptr
 
 @dataclass
 class LinkParams:
@@ -86,120 +79,73 @@ class LinkParams:
         return self.input_scaler / math.sqrt(self.var_x(ebno_db))
 
 
-def unit_qam_table(m):
-    """Unit-power square QAM, index = i*side + j <-> (pam[i], pam[j])  (driver:17-28)."""
-    side = math.ceil(math.sqrt(2 ** m) / 2) * 2
-    pam = np.arange(-(side - 1), side, 2).astype(float)
-    re, im = np.meshgrid(pam, pam, indexing="ij")
-    c = (re + 1j * im).reshape(-1)
-    return c / math.sqrt(np.mean(np.abs(c) ** 2))
-
-
 class FrameSource:
+    """HIP frame generator (esn_gen_taps / esn_gen_frames of include/esn_hip.h).  Counter-based
+    random streams: frame f of block b at SNR index s is a pure function of (seed, s, b, f)."""
+
+    CHANNEL_KIND = {"tdlb": 0, "exp": 1, "awgn": 2}
+
     def __init__(self, params: LinkParams, device=None, seed=0):
         torch = _lib.require_gpu()
         self.torch, self.p = torch, params
+        self.lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.seed = int(seed)
-        self.const = torch.as_tensor(unit_qam_table(params.m), device=self.device)
-        self.pow2 = (2 ** torch.arange(params.m, device=self.device)).view(1, 1, params.m, 1)
-        # TDL-B: h = g @ M with fixed split of each path between floor/ceil taps (driver:139-165)
-        p_lin = 10.0 ** (np.array(TDLB_POW_DB) / 10.0)
-        p_lin /= p_lin.sum()
-        d = np.array(TDLB_NORM_DELAYS) * params.ds_ns * 1e-9 * params.fs
-        M = np.zeros((len(p_lin), params.isi))
-        for k in range(len(p_lin)):
-            i0 = int(np.floor(d[k])); frac = d[k] - i0
-            if 0 <= i0 < params.isi:
-                M[k, i0] += 1.0 - frac
-            if 0 <= i0 + 1 < params.isi:
-                M[k, i0 + 1] += frac
-        self._tdl_M = torch.as_tensor(M * np.sqrt(p_lin)[:, None], device=self.device).to(torch.complex128)
-        pdp = np.exp(-np.arange(params.isi) / max(params.cp / 9, 1e-12))
-        self._exp_pdp = torch.as_tensor(np.sqrt(pdp / pdp.sum()), device=self.device)
 
-    def _gen(self, *key):
-        g = self.torch.Generator(device=self.device)
-        h = self.seed
-        for k in key:
-            h = (h * 1000003 + int(k) + 0x9E3779B9) % (2 ** 63 - 1)
-        g.manual_seed(h)
-        return g
+    def _key(self, *parts):
+        h = self.seed & (2 ** 64 - 1)
+        for k in parts:
+            h = (h * 6364136223846793005 + int(k) + 0x9E3779B97F4A7C15) % (2 ** 64)
+        return h
 
-    def _cn(self, shape, gen):
-        torch = self.torch
-        re = torch.randn(shape, generator=gen, device=self.device, dtype=torch.float64)
-        im = torch.randn(shape, generator=gen, device=self.device, dtype=torch.float64)
-        return torch.complex(re, im)
-
-    def taps(self, n_blocks, gen):
-        """[G, n_r, n_t, isi] complex128, i.i.d. links, unit energy per link (TDL-B)."""
+    def taps(self, n_blocks, snr_idx, first_block, gains=None):
+        """[G, n_r, n_t, isi] complex128.  Link l of block b draws from counter (first_block + b)."""
         torch, p = self.torch, self.p
-        if p.channel == "tdlb":
-            g = self._cn((n_blocks, p.n_r, p.n_t, self._tdl_M.shape[0]), gen) / math.sqrt(2.0)
-            h = g @ self._tdl_M
-            e = (h.abs() ** 2).sum(-1, keepdim=True)
-            return h / torch.sqrt(torch.where(e > 0, e, torch.ones_like(e)))
-        if p.channel == "exp":
-            return self._cn((n_blocks, p.n_r, p.n_t, p.isi), gen) / math.sqrt(2.0) * self._exp_pdp
-        if p.channel == "awgn":                      # flat unit-modulus channel (SISO driver :205-206)
-            h = self._cn((n_blocks, p.n_r, p.n_t, 1), gen)
-            h = h / h.abs()
-            return torch.cat([h, torch.zeros((n_blocks, p.n_r, p.n_t, p.isi - 1), dtype=h.dtype,
-                                             device=self.device)], -1)
-        raise ValueError(p.channel)
+        with torch.cuda.device(self.device):
+            out = torch.empty((n_blocks, p.n_r, p.n_t, p.isi), dtype=torch.complex128, device=self.device)
+            check(self.lib.esn_gen_taps(self.CHANNEL_KIND[p.channel], n_blocks, p.n_r, p.n_t, p.isi, p.fs, p.ds_ns,
+                                        ptr(gains), self._key(snr_idx, 1), int(first_block) * p.n_r * p.n_t,
+                                        ptr(out), _lib.stream_handle()), "esn_gen_taps")
+        return out
 
-    def transmit(self, n_frames, ebno_db, gen):
-        """bits [B, N*m, n_t] uint8, x_cp (pre-PA) and x_pa (post-PA) [B, T, n_t] complex128."""
+    def frames(self, taps, frames_per_block, ebno_db, snr_idx, first_frame, stream_id, want_x=False,
+               bits_in=None, noise_in=None):
+        """frames_per_block frames per block of `taps` -> (bits uint8 [B,N*m,n_t], x_cp or None, y_cp).
+        stream_id separates pilots (0) from data (1); first_frame is the global frame counter."""
         torch, p = self.torch, self.p
-        bits = (torch.rand((n_frames, p.n_sub * p.m, p.n_t), generator=gen, device=self.device) > 0.5)
-        idx = (bits.view(n_frames, p.n_sub, p.m, p.n_t).to(torch.int64) * self.pow2).sum(2)
-        x_f = self.const[idx]                                             # [B, N, n_t]
-        x_t = p.n_sub * torch.fft.ifft(x_f, dim=1)
-        if p.cp > 0:
-            x_t = torch.cat([x_t[:, -p.cp:], x_t], dim=1)
-        x_cp = x_t * math.sqrt(p.p_i(ebno_db))
-        x_pa = x_cp / torch.sqrt(1 + (x_cp.abs() / p.a_clip(ebno_db)) ** 2)
-        return bits.to(torch.uint8), x_cp, x_pa
-
-    def receive(self, x_pa, taps, frames_per_block, gen):
-        """y[b,t,rx] = sum_tx sum_k c[rx,tx,k] x[b,t-k,tx] + sqrt(T No/2)(randn + j randn)."""
-        torch, p = self.torch, self.p
-        b, t, _ = x_pa.shape
         g = taps.shape[0]
-        xp = torch.cat([torch.zeros((b, p.isi - 1, p.n_t), dtype=x_pa.dtype, device=self.device), x_pa], 1)
-        win = xp.unfold(1, p.isi, 1).flip(-1)                            # [B, T, n_t, isi]: x[t-k]
-        win = win.reshape(g, frames_per_block, t, p.n_t * p.isi)
-        c = taps.reshape(g, p.n_r, p.n_t * p.isi).transpose(1, 2)         # [G, n_t*isi, n_r]
-        y = torch.matmul(win.reshape(g, frames_per_block * t, -1), c).reshape(b, t, p.n_r)
-        return y + math.sqrt(t * p.no / 2) * self._cn((b, t, p.n_r), gen)
+        b = g * frames_per_block
+        with torch.cuda.device(self.device):
+            p_i = torch.full((g,), p.p_i(ebno_db), dtype=torch.float64, device=self.device)
+            a_clip = torch.full((g,), p.a_clip(ebno_db), dtype=torch.float64, device=self.device)
+            bits = torch.empty((b, p.n_sub * p.m, p.n_t), dtype=torch.uint8, device=self.device)
+            x_cp = torch.empty((b, p.t_frame, p.n_t), dtype=torch.complex128, device=self.device) if want_x else None
+            y_cp = torch.empty((b, p.t_frame, p.n_r), dtype=torch.complex128, device=self.device)
+            check(self.lib.esn_gen_frames(b, frames_per_block, p.n_sub, p.cp, p.n_t, p.n_r, p.isi, p.m, ptr(p_i),
+                                          ptr(a_clip), p.no, ptr(taps), ptr(bits_in), ptr(noise_in),
+                                          self._key(snr_idx, 2 + stream_id), int(first_frame), ptr(bits), ptr(x_cp),
+                                          ptr(y_cp), _lib.stream_handle()), "esn_gen_frames")
+        return bits, x_cp, y_cp
 
     def blocks(self, ebno_db, snr_idx, block_ids, frames_per_block):
-        """Pilot + data frames of the given coherence blocks.  Returns a dict of device tensors:
-        pilot_y [G,T,n_r], pilot_x [G,T,n_t] (pre-PA teacher), data_y [G*F,T,n_r], data_bits."""
+        """Pilot + data frames of the given coherence blocks (any subset, any order: every block is
+        generated from its own global index, so the result does not depend on the rank that asks).
+        Returns pilot_y [G,T,n_r], pilot_x [G,T,n_t] (pre-PA teacher), data_y [G*F,T,n_r], data_bits."""
         torch = self.torch
-        outs = []
-        for bid in block_ids:                     # one generator per block: rank-independent
-            gen = self._gen(snr_idx, bid)
-            taps = self.taps(1, gen)
-            _, px, ppa = self.transmit(1, ebno_db, gen)
-            py = self.receive(ppa, taps, 1, gen)
-            bits, _, dpa = self.transmit(frames_per_block, ebno_db, gen)
-            dy = self.receive(dpa, taps, frames_per_block, gen)
-            outs.append((py, px, dy, bits))
-        return dict(pilot_y=torch.cat([o[0] for o in outs]), pilot_x=torch.cat([o[1] for o in outs]),
-                    data_y=torch.cat([o[2] for o in outs]), data_bits=torch.cat([o[3] for o in outs]))
+        ids = list(block_ids)
+        runs, start = [], 0                          # contiguous runs of block ids -> one launch each
+        for i in range(1, len(ids) + 1):
+            if i == len(ids) or ids[i] != ids[i - 1] + 1:
+                runs.append((ids[start], i - start)); start = i
+        outs = [self.blocks_fast(ebno_db, snr_idx, b0, n, frames_per_block) for b0, n in runs]
+        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
 
     def blocks_fast(self, ebno_db, snr_idx, first_block, n_blocks, frames_per_block):
-        """Same recipe, all blocks from ONE generator keyed by (snr, first_block) -- for benchmarks,
-        where only shapes and statistics matter (not rank-independent per block)."""
-        gen = self._gen(snr_idx, first_block, n_blocks)
-        taps = self.taps(n_blocks, gen)
-        _, px, ppa = self.transmit(n_blocks, ebno_db, gen)
-        py = self.receive(ppa, taps, 1, gen)
-        bits, _, dpa = self.transmit(n_blocks * frames_per_block, ebno_db, gen)
-        dy = self.receive(dpa, taps, frames_per_block, gen)
-        return dict(pilot_y=py, pilot_x=px, data_y=dy, data_bits=bits)
+        """Blocks first_block .. first_block + n_blocks - 1 in three launches (taps, pilots, data)."""
+        taps = self.taps(n_blocks, snr_idx, first_block)
+        _, px, py = self.frames(taps, 1, ebno_db, snr_idx, first_block, 0, want_x=True)
+        bits, _, dy = self.frames(taps, frames_per_block, ebno_db, snr_idx, first_block * frames_per_block, 1)
+        return dict(pilot_y=py, pilot_x=px, data_y=dy, data_bits=bits, taps=taps)
 
 
 def _view_real(z):

@@ -29,6 +29,7 @@
  *                           extended states [states, inputs_scaled].
  *   esn_readout_solve_batch, esn_readout_solve_chol_batch
  *                           pinv solve of ESN.fit (:191-192).
+ *   esn_gen_taps, esn_gen_frames   transmitter + channel + noise of the drivers (:127-177, :397-427).
  *   esn_detect_count        driver tail: reconstruct (:47-58 of the 4x8 driver),
  *                           (1/N) FFT / sqrt(Pi) (:439-441), hard decision
  *                           (:95-103), bit-error count (:451-456).
@@ -172,6 +173,29 @@ int esn_detect_count(const double* Y, int n_frames, int frames_per_group,
                      const double* p_i, const uint8_t* tx_bits,
                      long long* err_count, long long* bit_count,
                      double* X_hat, void* stream);
+
+/* ---- Monte-Carlo frame generator: the producer directly upstream of the detector.
+ * float64 / complex128 like the reference; counter-based random streams keyed by
+ * (seed, global frame / link index), so a frame is identical on any rank and launch shape.
+ * Each random input may instead be supplied (bits_in, noise_in, gains_in = standard normals):
+ * the deterministic mode the parity tests use.
+ *
+ * esn_gen_taps   per-link impulse responses [n_blocks][n_r][n_t][isi] complex128:
+ *                kind 0 TDL-B (Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:127-177: 23 paths, delays
+ *                tau*DS*fs split linearly between floor/ceil taps, CN(0,p) gains, unit energy),
+ *                kind 1 exponential-PDP Rayleigh (OFDM_MIMO_2-2_NBF_LDPC.py:162-164,272-279),
+ *                kind 2 flat unit-modulus (Demo_SISO_QPSK_AWGN_LDPC_ESN_with_ZF_LS.py:205-206).
+ * esn_gen_frames bits -> 2^m-QAM (:406-411) -> N*ifft (:416) -> CP (:417) -> sqrt(Pi) -> PA (:419)
+ *                -> per-link FIR with zero initial state (:422-425) -> AWGN sqrt(T No/2) (:426).
+ *                p_i / a_clip are per block [n_blocks]; x_cp (pre-PA teacher) may be NULL. */
+int esn_gen_taps(int kind, int n_blocks, int n_r, int n_t, int isi, double fs_hz, double ds_ns,
+                 const double* gains_in, uint64_t seed, uint64_t link_offset,
+                 double* taps, void* stream);
+int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_t, int n_r, int isi,
+                   int bits_per_sym, const double* p_i, const double* a_clip, double no,
+                   const double* taps, const uint8_t* bits_in, const double* noise_in,
+                   uint64_t seed, uint64_t frame_offset,
+                   uint8_t* bits, double* x_cp, double* y_cp, void* stream);
 
 #ifdef __cplusplus
 }
