@@ -28,7 +28,8 @@ def build_library(force=False, verbose=True, stamps=False):
     s_memtime phase stamps; never used for timing or by the product)."""
     global LIB
     if stamps:
-        return _build(os.path.join(PKG, "libesn_hip_stamps.so"), "build_stamps", ["-DESN_STAMPS"], verbose)
+        extra = ["-DESN_STAMPS"] + os.environ.get("ESN_EXTRA_FLAGS", "").split()
+        return _build(os.path.join(PKG, "libesn_hip_stamps.so"), "build_stamps", extra, verbose)
     if not force and not _stale():
         return LIB
     return _build(LIB, "build", [], verbose)

@@ -425,7 +425,11 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             const int kg = kg_of(pos);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
+#ifdef ESN_NT_WEIGHTS   // measured: non-temporal weight loads are 1.5x SLOWER in G1 (every CU re-reads W from L2)
+                a[mt] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + ((size_t)mt * nkg + kg) * 1024));
+#else
                 a[mt] = *reinterpret_cast<const u32x4*>(wp + ((size_t)mt * nkg + kg) * 1024);
+#endif
         };
         auto loadB = [&](u32x4 (&b)[NT], int pos) {
             const int kg = kg_of(pos);

@@ -14,8 +14,9 @@ import torch  # noqa: E402
 
 from esn_ofdm_mimo_amd import _lib, build  # noqa: E402
 
-build.build_library(stamps=True, verbose=False)
-_lib.LIB_PATH = os.path.join(ROOT, "esn_ofdm_mimo_amd", "libesn_hip_stamps.so")
+if "ESN_STAMPS_LIB" not in os.environ:
+    build.build_library(stamps=True, verbose=False)
+_lib.LIB_PATH = os.path.join(ROOT, "esn_ofdm_mimo_amd", os.environ.get("ESN_STAMPS_LIB", "libesn_hip_stamps.so"))
 from esn_ofdm_mimo_amd.montecarlo import DetectorSweep, LinkParams  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16"
