@@ -226,7 +226,6 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     double* Gs = reinterpret_cast<double*>(chol_smem);            // [CH_NP][CH_LD]   (phase 2+)
     double* As = Gs;                                               // [CH_KC][CH_NP+4] (phase 1, aliased)
     double* Bs = Gs + CH_NP * CH_LD;                               // [nrhs][CH_NP] rhs / solution
-    __shared__ double sh_d[2];
     __shared__ int sh_bad;
     const int g = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -333,57 +332,59 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     __syncthreads();
     const double piv_tol = fmax(sh_max[0], sh_max[1]) * 1e-14;
 
-    // ---- phase 3: left-looking Cholesky, 8 threads per row, one column per iteration ----
+    // ---- phase 3: right-looking Cholesky, reduction-free ---------------------------------
+    // column j is snapshotted, then (i) scaled into L[:, j] and (ii) its rank-1 term removed from
+    // the trailing lower triangle, 8 threads per row; 1/L[j][j] is kept for the substitutions
+    __shared__ double sh_col[CH_NP], sh_invd[CH_NP];
     const int ri = tid >> 3, part = tid & 7;         // row 0..127
     for (int j = 0; j < ((sp.skip & 2) ? 1 : n); ++j) {
-        double s = 0.0;
-        if (ri >= j && ri < n) {
-            const double* Li = Gs + ri * CH_LD;
-            const double* Lj = Gs + j * CH_LD;
-            for (int k = part; k < j; k += 8) s = fma(Li[k], Lj[k], s);
-        }
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-        double v = 0.0;
-        if (ri >= j && ri < n) v = Gs[ri * CH_LD + j] - s;
-        if (ri == j && part == 0) {
-            if (!(v > piv_tol)) { sh_bad = 1; v = 1.0; sh_d[0] = 0.0; } else { sh_d[0] = 1.0; }
-            sh_d[1] = sqrt(v);
-        }
+        if (tid < n) sh_col[tid] = (tid >= j) ? Gs[tid * CH_LD + j] : 0.0;
         __syncthreads();
-        const double d = sh_d[1];
-        if (ri >= j && ri < n && part == 0) {
-            // a rejected pivot zeroes its column (the direction is dropped, as pinv would)
-            Gs[ri * CH_LD + j] = (ri == j) ? d : (sh_d[0] != 0.0 ? v / d : 0.0);
+        const double v = sh_col[j];
+        const bool ok = v > piv_tol;
+        if (tid == 0 && !ok) sh_bad = 1;
+        // a rejected pivot zeroes its column (the direction is dropped, as pinv would)
+        const double d = ok ? sqrt(v) : 1.0, inv_v = ok ? 1.0 / v : 0.0, inv_d = ok ? 1.0 / d : 0.0;
+        if (tid == j) { Gs[j * CH_LD + j] = d; sh_invd[j] = ok ? inv_d : 1.0; }
+        if (tid > j && tid < n) Gs[tid * CH_LD + j] = sh_col[tid] * inv_d;
+        if (ri > j && ri < n) {
+            const double ci = sh_col[ri] * inv_v;
+            double* Gi = Gs + ri * CH_LD;
+            for (int k = j + 1 + part; k <= ri; k += 8) Gi[k] = fma(-ci, sh_col[k], Gi[k]);
         }
         __syncthreads();
     }
 
-    // ---- phase 4: L L^T x = b, one wave per right-hand side ------------------------------
+    // ---- phase 4: L L^T x = b, column-oriented (no reductions), one wave per right-hand side --
     for (int o = wv; o < ((sp.skip & 4) ? 0 : nrhs); o += 16) {
         double* x = Bs + o * CH_NP;
-        for (int j = 0; j < n; ++j) {
-            const double* Lj = Gs + j * CH_LD;
-            double a = 0.0;
-            for (int k = lane; k < j; k += 64) a = fma(Lj[k], x[k], a);
-            a = wave_sum(a);
-            if (lane == 0) x[j] = (x[j] - a) / Lj[j];
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
+        double b0 = x[lane], b1 = x[lane + 64];       // rows lane and lane+64 of this rhs
+        for (int j = 0; j < n; ++j) {                 // forward: L z = b
+            const double own = (j < 64) ? b0 : b1;
+            const double zj = __shfl(own, j & 63) * sh_invd[j];
+            if (lane == (j & 63)) { if (j < 64) b0 = zj; else b1 = zj; }
+            const double l0 = (lane > j) ? Gs[lane * CH_LD + j] : 0.0;
+            const double l1 = (lane + 64 > j && lane + 64 < n) ? Gs[(lane + 64) * CH_LD + j] : 0.0;
+            b0 = fma(-l0, zj, b0);
+            b1 = fma(-l1, zj, b1);
         }
-        for (int j = n - 1; j >= 0; --j) {
-            double a = 0.0;
-            for (int k = j + 1 + lane; k < n; k += 64) a = fma(Gs[k * CH_LD + j], x[k], a);
-            a = wave_sum(a);
-            if (lane == 0) x[j] = (x[j] - a) / Gs[j * CH_LD + j];
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
+        for (int j = n - 1; j >= 0; --j) {            // backward: L^T x = z
+            const double own = (j < 64) ? b0 : b1;
+            const double xj = __shfl(own, j & 63) * sh_invd[j];
+            if (lane == (j & 63)) { if (j < 64) b0 = xj; else b1 = xj; }
+            const double* Lj = Gs + j * CH_LD;        // row j: L[j][i], i < j
+            const double l0 = (lane < j) ? Lj[lane] : 0.0;
+            const double l1 = (lane + 64 < j) ? Lj[lane + 64] : 0.0;
+            b0 = fma(-l0, xj, b0);
+            b1 = fma(-l1, xj, b1);
         }
+        x[lane] = b0; x[lane + 64] = b1;
     }
     __syncthreads();
 
     // ---- phase 5: W_out ---------------------------------------------------------------------
     if (wide) {
-        // W_out[o][c] = sum_i A[i][c] alpha[i][o]
+        // W_out[o][c] = sum_i A[i][c] alpha[i][o]   (a hand-unrolled 8-loads-in-flight form measured slower)
         for (int e = tid; e < ((sp.skip & 8) ? 0 : nrhs * cols); e += 1024) {
             const int o = e / cols, c = e % cols;
             const double* al = Bs + o * CH_NP;
