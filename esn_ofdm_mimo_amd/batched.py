@@ -203,9 +203,13 @@ class ReservoirBank:
         U = _as_dev(U, torch, self.device)
         b, t_in = U.shape[0], U.shape[1]
         T = t_in if T is None else int(T)
+        if not (0 <= int(transient) < T and t_in <= T):
+            raise ValueError(f"need 0 <= transient < T and T_in <= T (transient={transient}, T_in={t_in}, T={T})")
         g = (b + frames_per_group - 1) // frames_per_group
         self._check_groups(g)
-        if self.W_out is None or self.W_out.shape[0] != g:
+        if self.W_out is None:
+            raise AttributeError("W_out: fit (or set_readout) before predict")
+        if self.W_out.shape[0] < g:
             raise ValueError(f"readout holds {None if self.W_out is None else self.W_out.shape[0]} groups, batch needs {g}")
         x0 = _as_dev(x0, torch, self.device)
         y0 = _as_dev(y0, torch, self.device)
@@ -246,7 +250,7 @@ class ReservoirBank:
     def _check_groups(self, g):
         for name in ("in_scale", "in_shift", "t_scale", "t_shift"):
             t = getattr(self, name)
-            if t is not None and t.shape[0] != g:
+            if t is not None and t.shape[0] < g:
                 raise ValueError(f"{name} holds {t.shape[0]} groups, batch has {g}")
         if self.n_wsets > 1 and g % self.n_wsets and g > self.n_wsets:
             pass  # weight set = group % n_wsets by contract

@@ -345,3 +345,46 @@ def test_f32_kernel_rejects_what_it_cannot_hold(amd):
     esn.W_out = np.zeros((2, 1102))
     with pytest.raises(_lib.EsnHipError, match="does not support"):
         esn.predict(np.zeros((2, 5, 2)), continuation=False, precision="f32")
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32", "f16", "bf16"])
+@pytest.mark.parametrize("n_in,n_out,tf", [(3, 5, True), (1, 1, True), (6, 12, True), (5, 2, False)])
+def test_odd_shapes_and_flags(amd, precision, n_in, n_out, tf):
+    """Shapes off the fast paths: odd n_in (no LDS-DMA, kin_p not a power of two), n_out > 8 (two
+    readout images in fp16), a single frame, transient = T-1, teacher_forcing off."""
+    _, _, batched = amd
+    rs = np.random.RandomState(100 * n_in + n_out)
+    n_res, t, G, F = 70, 17, 2, 3
+    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.8, 0.2)
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, teacher_forcing=tf, noise=0.0)
+    t_scale = rs.rand(G, n_out) + 0.5
+    bank.set_scaling(None, rs.randn(G, n_in) * 0.1, t_scale, None)
+    w_out = rs.randn(G, n_out, n_res + n_in) * 0.05
+    bank.set_readout(w_out)
+    u = rs.randn(G * F, t, n_in) * 0.5
+    tol = {"f64": 1e-10, "f32": 2e-5, "f16": 2e-2, "bf16": 2e-1}[precision]   # bf16: 8 significant bits
+    for tr in (0, t - 1):
+        got = bank.predict(u, F, transient=tr, precision=precision).cpu().numpy()
+        assert got.shape == (G * F, t - tr, n_out)
+        for b in range(G * F):
+            grp = b // F
+            o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_shift=bank.in_shift[grp].cpu().numpy(),
+                             teacher_scaling=t_scale[grp], teacher_forcing=tf, random_state=1)
+            o.W, o.W_in, o.W_feedb, o.W_out = w, w_in, w_fb, w_out[grp]
+            want = o.predict(u[b], tr, continuation=False)
+            assert rel_err(got[b], want) < tol, (precision, n_in, n_out, tr, b, rel_err(got[b], want))
+    one = bank.predict(u[:1], F, transient=0, precision=precision).cpu().numpy()     # a single frame
+    np.testing.assert_array_equal(one[0], bank.predict(u, F, transient=0, precision=precision).cpu().numpy()[0])
+
+
+def test_argument_validation_on_device(amd):
+    from esn_ofdm_mimo_amd import _lib
+    _, _, batched = amd
+    bank = batched.ReservoirBank(2, 2, 8, np.zeros((8, 8)), np.zeros((8, 2)), np.zeros((8, 2)), noise=0.0)
+    with pytest.raises(AttributeError):
+        bank.predict(np.zeros((2, 4, 2)), 2, precision="f64")          # predict before fit
+    bank.set_readout(np.zeros((1, 2, 10)))
+    with pytest.raises(ValueError, match="transient"):
+        bank.predict(np.zeros((2, 4, 2)), 2, transient=4, precision="f64")   # transient >= T
+    with pytest.raises(ValueError):
+        bank.predict(np.zeros((4, 4, 2)), 2, precision="f64")          # 2 groups, readout holds 1
