@@ -31,8 +31,8 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
         else return false;
     }
     // tuning knob (benchmarks only): ESN_MFMA_GEOM="NW,MT,NT" overrides the fp16/bf16 predict table
-    if (!harvest && es == 2) {
-        const char* ov = getenv("ESN_MFMA_GEOM");
+    if (!harvest) {
+        const char* ov = getenv(es == 2 ? "ESN_MFMA_GEOM" : "ESN_MFMA_GEOM_F32");
         int a, b, c;
         if (ov && sscanf(ov, "%d,%d,%d", &a, &b, &c) == 3 && 32 * a * b >= n_res) { NW = a; MT = b; NT = c; }
     }
