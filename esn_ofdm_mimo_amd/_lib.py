@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_PKG, "libesn_hip.so")
 F64, F32, F16, BF16 = 0, 1, 2, 3
 PRECISIONS = {"f64": F64, "f32": F32, "f16": F16, "bf16": BF16}
 NOISE_NONE, NOISE_TENSOR, NOISE_COUNTER = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Shape(C.Structure):
@@ -44,8 +44,12 @@ SIGNATURES = {
                                                _dp, _dp, _dp, _ip, _vp]),
     "esn_gen_taps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _dp,
                                C.c_uint64, C.c_uint64, _dp, _vp]),
-    "esn_gen_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "esn_gen_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  _dp, _dp, C.c_double, _dp, _vp, _dp, C.c_uint64, C.c_uint64, _vp, _dp, _dp, _vp]),
+    "esn_channel_estimate": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
+                                       C.c_double, _vp, _dp, _dp, _vp]),
+    "esn_mmse_detect_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
+                                        C.c_double, _dp, _dp, _vp, _vp, _vp, _dp, _vp]),
     "esn_detect_count": (C.c_int, [_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _vp,
                                    _vp, _vp, _dp, _vp]),
 }

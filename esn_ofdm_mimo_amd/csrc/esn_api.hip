@@ -32,6 +32,9 @@ int launch_readout_chol(const double* E, const double* D, int n_groups, int T, i
 // esn_gen.hip
 int launch_gen_taps(const TapParams& tp, hipStream_t stream);
 int launch_gen_frames(const FrameGenParams& fp, hipStream_t stream);
+// esn_baseline.hip
+int launch_channel_estimate(const ChanEstParams& cp, hipStream_t stream);
+int launch_mmse_detect(const MmseParams& mp, hipStream_t stream);
 // esn_detect.hip
 int launch_detect_count(const DetectParams& dp, hipStream_t stream);
 }  // namespace esn
@@ -84,7 +87,7 @@ extern "C" {
 
 const char* esn_last_error(void) { return g_err; }
 
-int esn_abi_version(void) { return 1; }
+int esn_abi_version(void) { return 2; }
 
 int esn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -299,7 +302,7 @@ int esn_gen_taps(int kind, int n_blocks, int n_r, int n_t, int isi, double fs_hz
 }
 
 int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_t, int n_r, int isi,
-                   int bits_per_sym, const double* p_i, const double* a_clip, double no, const double* taps,
+                   int bits_per_sym, int ls_pattern, const double* p_i, const double* a_clip, double no, const double* taps,
                    const uint8_t* bits_in, const double* noise_in, uint64_t seed, uint64_t frame_offset,
                    uint8_t* bits, double* x_cp, double* y_cp, void* stream) {
     if (!p_i || !a_clip || !taps || !bits || !y_cp) return fail(-1, "esn_gen_frames: null pointer");
@@ -316,9 +319,47 @@ int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_
     fp.cp = cp; fp.n_t = n_t; fp.n_r = n_r; fp.isi = isi; fp.m = bits_per_sym;
     fp.p_i = p_i; fp.a_clip = a_clip; fp.no = no; fp.taps = taps; fp.bits_in = bits_in; fp.noise_in = noise_in;
     fp.seed = seed; fp.frame_offset = frame_offset; fp.bits = bits; fp.x_cp = x_cp; fp.y_cp = y_cp;
+    fp.ls_pattern = ls_pattern ? 1 : 0;
     int e = launch_gen_frames(fp, (hipStream_t)stream);
     if (e == -1) return fail(-2, "esn_gen_frames: frame does not fit LDS");
     return hip_fail(e, "esn_gen_frames");
+}
+
+static int pow2_log(int n) { int l = 0; while ((1 << l) < n) ++l; return ((1 << l) == n) ? l : -1; }
+
+int esn_channel_estimate(int n_blocks, int n_sub, int cp, int n_t, int n_r, int isi, int bits_per_sym,
+                         const double* p_i, double no, const uint8_t* pilot_bits, const double* y_ls_cp,
+                         double* H, void* stream) {
+    if (!p_i || !pilot_bits || !y_ls_cp || !H) return fail(-1, "esn_channel_estimate: null pointer");
+    const int l2 = pow2_log(n_sub);
+    if (l2 < 1 || n_sub > 2048) return fail(-1, "esn_channel_estimate: N=%d must be a power of two in [2, 2048]", n_sub);
+    if (n_blocks <= 0 || cp < 0 || cp >= n_sub || n_t <= 0 || n_r <= 0 || isi <= 0 || isi > 64 || n_sub / n_t < 2 ||
+        bits_per_sym < 2 || (bits_per_sym & 1))
+        return fail(-1, "esn_channel_estimate: invalid sizes");
+    ChanEstParams c;
+    c.n_blocks = n_blocks; c.n_sub = n_sub; c.log2n = l2; c.cp = cp; c.n_t = n_t; c.n_r = n_r; c.isi = isi;
+    c.m = bits_per_sym; c.p_i = p_i; c.no = no; c.pilot_bits = pilot_bits; c.y_ls_cp = y_ls_cp; c.H = H;
+    return hip_fail(launch_channel_estimate(c, (hipStream_t)stream), "esn_channel_estimate");
+}
+
+int esn_mmse_detect_count(int n_frames, int frames_per_group, int n_sub, int cp, int n_t, int n_r, int bits_per_sym,
+                          const double* p_i, double no, const double* H, const double* y_cp,
+                          const uint8_t* tx_bits, long long* err_count, long long* bit_count, double* X_hat,
+                          void* stream) {
+    if (!p_i || !H || !y_cp || !tx_bits || !err_count || !bit_count)
+        return fail(-1, "esn_mmse_detect_count: null pointer");
+    const int l2 = pow2_log(n_sub);
+    if (l2 < 1 || n_sub > 2048) return fail(-1, "esn_mmse_detect_count: N=%d must be a power of two in [2, 2048]", n_sub);
+    if (n_frames <= 0 || frames_per_group <= 0 || cp < 0 || cp >= n_sub || n_t <= 0 || n_r <= 0 ||
+        bits_per_sym < 2 || (bits_per_sym & 1))
+        return fail(-1, "esn_mmse_detect_count: invalid sizes");
+    MmseParams m;
+    m.n_frames = n_frames; m.frames_per_group = frames_per_group; m.n_sub = n_sub; m.log2n = l2; m.cp = cp;
+    m.n_t = n_t; m.n_r = n_r; m.m = bits_per_sym; m.p_i = p_i; m.no = no; m.H = H; m.y_cp = y_cp;
+    m.tx_bits = tx_bits; m.err = err_count; m.bits = bit_count; m.X_hat = X_hat;
+    int e = launch_mmse_detect(m, (hipStream_t)stream);
+    if (e == -1) return fail(-2, "esn_mmse_detect_count: needs n_t <= 4 and n_r * N * 16 bytes of LDS");
+    return hip_fail(e, "esn_mmse_detect_count");
 }
 
 }  // extern "C"

@@ -84,6 +84,24 @@ struct FrameGenParams {
     uint8_t* bits;            // [B][N*m][n_t]
     double* x_cp;             // optional complex [B][T][n_t] (pre-PA: the ESN teacher)
     double* y_cp;             // complex [B][T][n_r]
+    int ls_pattern;           // 1: sparse LS pilot, subcarrier sc carries only tx = sc % n_t (driver:330-333)
+};
+
+// baseline equaliser (esn_baseline.hip)
+struct ChanEstParams {
+    int n_blocks, n_sub, log2n, cp, n_t, n_r, isi, m;
+    const double* p_i; double no;
+    const uint8_t* pilot_bits;   // [G][N*m][n_t]
+    const double* y_ls_cp;       // complex [G][T][n_r]
+    double* H;                   // complex [G][N][n_r][n_t]
+};
+struct MmseParams {
+    int n_frames, frames_per_group, n_sub, log2n, cp, n_t, n_r, m;
+    const double* p_i; double no;
+    const double* H;             // complex [G][N][n_r][n_t]
+    const double* y_cp;          // complex [B][T][n_r]
+    const uint8_t* tx_bits;      // [B][N*m][n_t]
+    long long* err; long long* bits; double* X_hat;
 };
 
 // slot -> frame index (or -1 for padding) and its group

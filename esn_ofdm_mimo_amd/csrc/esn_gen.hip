@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
             fp.bits[((size_t)frame * N * m + (size_t)sc * m + b) * n_t + tx] = (uint8_t)((idx >> b) & 1);
         const int pi_ = (int)(idx / side), pj = (int)(idx % side);
         const int rv = (int)(__brev((unsigned)sc) >> (32 - fp.log2n));
-        X[(size_t)tx * N + rv] = make_double2((2.0 * pi_ - (side - 1)) / norm, (2.0 * pj - (side - 1)) / norm);
+        const bool on = !fp.ls_pattern || (sc % n_t == tx);
+        X[(size_t)tx * N + rv] = on ? make_double2((2.0 * pi_ - (side - 1)) / norm, (2.0 * pj - (side - 1)) / norm)
+                                    : make_double2(0.0, 0.0);
     }
     __syncthreads();
     // ---- x = N * ifft(X): un-normalised inverse DFT, radix-2 DIT on bit-reversed input, per tx

@@ -109,7 +109,7 @@ class FrameSource:
         return out
 
     def frames(self, taps, frames_per_block, ebno_db, snr_idx, first_frame, stream_id, want_x=False,
-               bits_in=None, noise_in=None):
+               bits_in=None, noise_in=None, ls_pattern=False):
         """frames_per_block frames per block of `taps` -> (bits uint8 [B,N*m,n_t], x_cp or None, y_cp).
         stream_id separates pilots (0) from data (1); first_frame is the global frame counter."""
         torch, p = self.torch, self.p
@@ -121,13 +121,14 @@ class FrameSource:
             bits = torch.empty((b, p.n_sub * p.m, p.n_t), dtype=torch.uint8, device=self.device)
             x_cp = torch.empty((b, p.t_frame, p.n_t), dtype=torch.complex128, device=self.device) if want_x else None
             y_cp = torch.empty((b, p.t_frame, p.n_r), dtype=torch.complex128, device=self.device)
-            check(self.lib.esn_gen_frames(b, frames_per_block, p.n_sub, p.cp, p.n_t, p.n_r, p.isi, p.m, ptr(p_i),
+            check(self.lib.esn_gen_frames(b, frames_per_block, p.n_sub, p.cp, p.n_t, p.n_r, p.isi, p.m,
+                                          1 if ls_pattern else 0, ptr(p_i),
                                           ptr(a_clip), p.no, ptr(taps), ptr(bits_in), ptr(noise_in),
                                           self._key(snr_idx, 2 + stream_id), int(first_frame), ptr(bits), ptr(x_cp),
                                           ptr(y_cp), _lib.stream_handle()), "esn_gen_frames")
         return bits, x_cp, y_cp
 
-    def blocks(self, ebno_db, snr_idx, block_ids, frames_per_block):
+    def blocks(self, ebno_db, snr_idx, block_ids, frames_per_block, with_ls_pilot=False):
         """Pilot + data frames of the given coherence blocks (any subset, any order: every block is
         generated from its own global index, so the result does not depend on the rank that asks).
         Returns pilot_y [G,T,n_r], pilot_x [G,T,n_t] (pre-PA teacher), data_y [G*F,T,n_r], data_bits."""
@@ -137,15 +138,49 @@ class FrameSource:
         for i in range(1, len(ids) + 1):
             if i == len(ids) or ids[i] != ids[i - 1] + 1:
                 runs.append((ids[start], i - start)); start = i
-        outs = [self.blocks_fast(ebno_db, snr_idx, b0, n, frames_per_block) for b0, n in runs]
+        outs = [self.blocks_fast(ebno_db, snr_idx, b0, n, frames_per_block, with_ls_pilot) for b0, n in runs]
         return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
 
-    def blocks_fast(self, ebno_db, snr_idx, first_block, n_blocks, frames_per_block):
+    def blocks_fast(self, ebno_db, snr_idx, first_block, n_blocks, frames_per_block, with_ls_pilot=False):
         """Blocks first_block .. first_block + n_blocks - 1 in three launches (taps, pilots, data)."""
         taps = self.taps(n_blocks, snr_idx, first_block)
-        _, px, py = self.frames(taps, 1, ebno_db, snr_idx, first_block, 0, want_x=True)
+        pbits, px, py = self.frames(taps, 1, ebno_db, snr_idx, first_block, 0, want_x=True)
         bits, _, dy = self.frames(taps, frames_per_block, ebno_db, snr_idx, first_block * frames_per_block, 1)
-        return dict(pilot_y=py, pilot_x=px, data_y=dy, data_bits=bits, taps=taps)
+        out = dict(pilot_y=py, pilot_x=px, pilot_bits=pbits, data_y=dy, data_bits=bits, taps=taps)
+        if with_ls_pilot:     # same bits, same noise, sparse pattern (driver:330-356)
+            _, _, out["pilot_y_ls"] = self.frames(taps, 1, ebno_db, snr_idx, first_block, 0, ls_pattern=True)
+        return out
+
+    # ---- baseline equaliser (SURVEY 8f-3) ------------------------------------------------------
+    def estimate_channel(self, pilot_bits, pilot_y_ls, ebno_db):
+        """LS + time-domain MMSE channel estimate H [G, N, n_r, n_t] (driver:358-382)."""
+        torch, p = self.torch, self.p
+        g = pilot_bits.shape[0]
+        with torch.cuda.device(self.device):
+            p_i = torch.full((g,), p.p_i(ebno_db), dtype=torch.float64, device=self.device)
+            H = torch.empty((g, p.n_sub, p.n_r, p.n_t), dtype=torch.complex128, device=self.device)
+            check(self.lib.esn_channel_estimate(g, p.n_sub, p.cp, p.n_t, p.n_r, p.isi, p.m, ptr(p_i), p.no,
+                                                ptr(pilot_bits.contiguous()), ptr(pilot_y_ls.contiguous()), ptr(H),
+                                                _lib.stream_handle()), "esn_channel_estimate")
+        return H
+
+    def mmse_detect_count(self, H, data_y, data_bits, frames_per_block, ebno_db, err=None, bits=None,
+                          want_xhat=False):
+        """Per-subcarrier MMSE detector + error counters (driver:444-456)."""
+        torch, p = self.torch, self.p
+        g, b = H.shape[0], data_y.shape[0]
+        with torch.cuda.device(self.device):
+            p_i = torch.full((g,), p.p_i(ebno_db), dtype=torch.float64, device=self.device)
+            if err is None:
+                err = torch.zeros(g, dtype=torch.int64, device=self.device)
+            if bits is None:
+                bits = torch.zeros(g, dtype=torch.int64, device=self.device)
+            xh = torch.empty((b, p.n_sub, p.n_t), dtype=torch.complex128, device=self.device) if want_xhat else None
+            check(self.lib.esn_mmse_detect_count(b, int(frames_per_block), p.n_sub, p.cp, p.n_t, p.n_r, p.m,
+                                                 ptr(p_i), p.no, ptr(H), ptr(data_y.contiguous()),
+                                                 ptr(data_bits.contiguous()), ptr(err), ptr(bits), ptr(xh),
+                                                 _lib.stream_handle()), "esn_mmse_detect_count")
+        return (err, bits, xh) if want_xhat else (err, bits)
 
 
 def _view_real(z):

@@ -30,6 +30,7 @@
  *   esn_readout_solve_batch, esn_readout_solve_chol_batch
  *                           pinv solve of ESN.fit (:191-192).
  *   esn_gen_taps, esn_gen_frames   transmitter + channel + noise of the drivers (:127-177, :397-427).
+ *   esn_channel_estimate, esn_mmse_detect_count   LS/MMSE baseline (:358-382, :40-45, :444-448).
  *   esn_detect_count        driver tail: reconstruct (:47-58 of the 4x8 driver),
  *                           (1/N) FFT / sqrt(Pi) (:439-441), hard decision
  *                           (:95-103), bit-error count (:451-456).
@@ -187,15 +188,34 @@ int esn_detect_count(const double* Y, int n_frames, int frames_per_group,
  *                kind 2 flat unit-modulus (Demo_SISO_QPSK_AWGN_LDPC_ESN_with_ZF_LS.py:205-206).
  * esn_gen_frames bits -> 2^m-QAM (:406-411) -> N*ifft (:416) -> CP (:417) -> sqrt(Pi) -> PA (:419)
  *                -> per-link FIR with zero initial state (:422-425) -> AWGN sqrt(T No/2) (:426).
- *                p_i / a_clip are per block [n_blocks]; x_cp (pre-PA teacher) may be NULL. */
+ *                p_i / a_clip are per block [n_blocks]; x_cp (pre-PA teacher) may be NULL.
+ *                ls_pattern = 1 keeps only tx = sc % n_t on subcarrier sc (the sparse LS pilot of
+ *                :330-333); with the pilot's seed / frame index it shares the pilot's bits AND noise
+ *                (:354-356), as the reference does. */
 int esn_gen_taps(int kind, int n_blocks, int n_r, int n_t, int isi, double fs_hz, double ds_ns,
                  const double* gains_in, uint64_t seed, uint64_t link_offset,
                  double* taps, void* stream);
 int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_t, int n_r, int isi,
-                   int bits_per_sym, const double* p_i, const double* a_clip, double no,
+                   int bits_per_sym, int ls_pattern, const double* p_i, const double* a_clip, double no,
                    const double* taps, const uint8_t* bits_in, const double* noise_in,
                    uint64_t seed, uint64_t frame_offset,
                    uint8_t* bits, double* x_cp, double* y_cp, void* stream);
+
+/* ---- Baseline equaliser the reference compares the ESN with, float64.
+ * esn_channel_estimate   pilot_bits [G][N*m][n_t], y_ls_cp complex [G][T][n_r] (received sparse LS
+ *                        pilot) -> H complex [G][N][n_r][n_t]: LS at sc = tx + n_t i, linear
+ *                        inter/extrapolation, IFFT -> isi taps, diagonal MMSE shrinkage, DFT
+ *                        (Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:358-382).
+ * esn_mmse_detect_count  y_cp complex [B][T][n_r] -> X = (H^H H + No/Pi I)^-1 H^H Y / sqrt(Pi) per
+ *                        subcarrier (:40-45, :444-448), hard decision + error count as in
+ *                        esn_detect_count; n_t <= 4.  X_hat complex [B][N][n_t] optional. */
+int esn_channel_estimate(int n_blocks, int n_sub, int cp, int n_t, int n_r, int isi, int bits_per_sym,
+                         const double* p_i, double no, const uint8_t* pilot_bits,
+                         const double* y_ls_cp, double* H, void* stream);
+int esn_mmse_detect_count(int n_frames, int frames_per_group, int n_sub, int cp, int n_t, int n_r,
+                          int bits_per_sym, const double* p_i, double no, const double* H,
+                          const double* y_cp, const uint8_t* tx_bits,
+                          long long* err_count, long long* bit_count, double* X_hat, void* stream);
 
 #ifdef __cplusplus
 }
