@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_PKG, "libesn_hip.so")
 F64, F32, F16, BF16 = 0, 1, 2, 3
 PRECISIONS = {"f64": F64, "f32": F32, "f16": F16, "bf16": BF16}
 NOISE_NONE, NOISE_TENSOR, NOISE_COUNTER = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Shape(C.Structure):
@@ -50,6 +50,10 @@ SIGNATURES = {
                                        C.c_double, _vp, _dp, _dp, _vp]),
     "esn_mmse_detect_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
                                         C.c_double, _dp, _dp, _vp, _vp, _vp, _dp, _vp]),
+    "esn_ldpc_encode": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "esn_qam_llr": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _vp]),
+    "esn_ldpc_decode_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _dp,
+                                        C.c_double, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "esn_detect_count": (C.c_int, [_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _vp,
                                    _vp, _vp, _dp, _vp]),
 }

@@ -35,6 +35,10 @@ int launch_gen_frames(const FrameGenParams& fp, hipStream_t stream);
 // esn_baseline.hip
 int launch_channel_estimate(const ChanEstParams& cp, hipStream_t stream);
 int launch_mmse_detect(const MmseParams& mp, hipStream_t stream);
+// esn_coded.hip
+int launch_ldpc_encode(const LdpcEncodeParams& ep, hipStream_t stream);
+int launch_qam_llr(const LlrParams& lp, hipStream_t stream);
+int launch_ldpc_decode(const LdpcDecodeParams& dp, hipStream_t stream);
 // esn_detect.hip
 int launch_detect_count(const DetectParams& dp, hipStream_t stream);
 }  // namespace esn
@@ -87,7 +91,7 @@ extern "C" {
 
 const char* esn_last_error(void) { return g_err; }
 
-int esn_abi_version(void) { return 2; }
+int esn_abi_version(void) { return 3; }
 
 int esn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -360,6 +364,44 @@ int esn_mmse_detect_count(int n_frames, int frames_per_group, int n_sub, int cp,
     int e = launch_mmse_detect(m, (hipStream_t)stream);
     if (e == -1) return fail(-2, "esn_mmse_detect_count: needs n_t <= 4 and n_r * N * 16 bytes of LDS");
     return hip_fail(e, "esn_mmse_detect_count");
+}
+
+int esn_ldpc_encode(int n_frames, int n_t, int k, int n, const uint8_t* P, const uint8_t* u, uint8_t* bits,
+                    void* stream) {
+    if (!P || !u || !bits) return fail(-1, "esn_ldpc_encode: null pointer");
+    if (n_frames <= 0 || n_t <= 0 || k <= 0 || k >= n || k > 60000) return fail(-1, "esn_ldpc_encode: invalid sizes");
+    LdpcEncodeParams ep;
+    ep.n_frames = n_frames; ep.n_t = n_t; ep.k = k; ep.n = n; ep.P = P; ep.u = u; ep.bits = bits;
+    return hip_fail(launch_ldpc_encode(ep, (hipStream_t)stream), "esn_ldpc_encode");
+}
+
+int esn_qam_llr(int n_frames, int n_sub, int n_t, int bits_per_sym, const double* X_hat, double* llr,
+                double* sigma2, void* stream) {
+    if (!X_hat || !llr) return fail(-1, "esn_qam_llr: null pointer");
+    if (n_frames <= 0 || n_sub <= 0 || n_t <= 0 || bits_per_sym < 2 || bits_per_sym > 10 || (bits_per_sym & 1))
+        return fail(-1, "esn_qam_llr: invalid sizes");
+    LlrParams lp;
+    lp.n_frames = n_frames; lp.n_sub = n_sub; lp.n_t = n_t; lp.m = bits_per_sym; lp.X_hat = X_hat; lp.llr = llr;
+    lp.sigma2 = sigma2;
+    return hip_fail(launch_qam_llr(lp, (hipStream_t)stream), "esn_qam_llr");
+}
+
+int esn_ldpc_decode_count(int n_cw, int n, int k, int m_checks, int n_edges, const int* chk_ptr, const int* edge_var,
+                          const int* var_ptr, const int* var_edge, const double* y, double snr_db, int maxiter,
+                          const uint8_t* u_true, int cw_per_group, uint8_t* x_out, long long* err_count,
+                          long long* bit_count, void* stream) {
+    if (!chk_ptr || !edge_var || !var_ptr || !var_edge || !y) return fail(-1, "esn_ldpc_decode_count: null pointer");
+    if (u_true && (!err_count || !bit_count)) return fail(-1, "esn_ldpc_decode_count: counters missing");
+    if (n_cw <= 0 || n <= 0 || k <= 0 || k > n || m_checks <= 0 || n_edges <= 0 || maxiter <= 0 || cw_per_group <= 0)
+        return fail(-1, "esn_ldpc_decode_count: invalid sizes");
+    LdpcDecodeParams dp;
+    dp.n_cw = n_cw; dp.n = n; dp.k = k; dp.m_checks = m_checks; dp.n_edges = n_edges; dp.maxiter = maxiter;
+    dp.cw_per_group = cw_per_group; dp.var = pow(10.0, -snr_db / 10.0);
+    dp.chk_ptr = chk_ptr; dp.edge_var = edge_var; dp.var_ptr = var_ptr; dp.var_edge = var_edge; dp.y = y;
+    dp.u_true = u_true; dp.x_out = x_out; dp.err = err_count; dp.bits = bit_count;
+    int e = launch_ldpc_decode(dp, (hipStream_t)stream);
+    if (e == -1) return fail(-2, "esn_ldpc_decode_count: graph does not fit LDS (16 B per edge)");
+    return hip_fail(e, "esn_ldpc_decode_count");
 }
 
 }  // extern "C"

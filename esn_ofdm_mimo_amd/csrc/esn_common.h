@@ -104,6 +104,32 @@ struct MmseParams {
     long long* err; long long* bits; double* X_hat;
 };
 
+// coded leg (esn_coded.hip)
+struct LdpcEncodeParams {
+    int n_frames, n_t, k, n;
+    const uint8_t* P;        // [n-k][k] parity part of the systematic generator (bytes 0/1)
+    const uint8_t* u;        // [B][n_t][k] information bits
+    uint8_t* bits;           // [B][n][n_t]  (TxBits layout, n = N*m)
+};
+struct LlrParams {
+    int n_frames, n_sub, n_t, m;
+    const double* X_hat;     // complex [B][N][n_t]
+    double* llr;             // [B][n_t][N*m]
+    double* sigma2;          // optional [B]
+};
+struct LdpcDecodeParams {
+    int n_cw, n, k, m_checks, n_edges, maxiter, cw_per_group;
+    double var;              // 10^(-snr_db/10)
+    const int* chk_ptr;      // [m_checks+1] edges of check c: chk_ptr[c] .. chk_ptr[c+1]
+    const int* edge_var;     // [E] variable of edge e (check-major order)
+    const int* var_ptr;      // [n+1]
+    const int* var_edge;     // [E] edge ids of variable v
+    const double* y;         // [n_cw][n] observations (bit 0 <-> +)
+    const uint8_t* u_true;   // optional [n_cw][k]
+    uint8_t* x_out;          // optional [n_cw][n]
+    long long* err; long long* bits;
+};
+
 // slot -> frame index (or -1 for padding) and its group
 __device__ __forceinline__ int slot_frame(const RecurParams& p, int slot, int& grp) {
     grp = slot / p.Fpad;

@@ -217,6 +217,28 @@ int esn_mmse_detect_count(int n_frames, int frames_per_group, int n_sub, int cp,
                           const double* y_cp, const uint8_t* tx_bits,
                           long long* err_count, long long* bit_count, double* X_hat, void* stream);
 
+/* ---- Coded leg of the north-star driver, float64.  The reference delegates the code
+ * to the un-vendored package pyldpc (requirements-sm2.txt:5); these entry points restate its
+ * published algorithms at the reference's call sites (parity unpinned, see oracle/ldpc_oracle.py).
+ * esn_ldpc_encode        c = [u ; P u mod 2] per (frame, tx) into TxBits [B][n][n_t], n = N*m
+ *                        (Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:90-93, :399-404); P [n-k][k] bytes.
+ * esn_qam_llr            X_hat complex [B][N][n_t] -> max-log LLRs [B][n_t][N*m] (positive = bit 0)
+ *                        scaled by the decision-directed sigma^2 of the frame (:66-88, :108-112, :459-469).
+ * esn_ldpc_decode_count  pyldpc.decode: flooding log-domain sum-product on y [n_cw][n] with
+ *                        var = 10^(-snr_db/10), Lc = 2 y / var, at most maxiter sweeps, early stop on a
+ *                        zero syndrome (:495-496); message = first k bits (get_message); info-bit
+ *                        errors vs u_true accumulated per group of cw_per_group codewords (:508-511).
+ *                        Graph in CSR form: chk_ptr [m+1], edge_var [E] (check-major), var_ptr [n+1],
+ *                        var_edge [E]. */
+int esn_ldpc_encode(int n_frames, int n_t, int k, int n, const uint8_t* P, const uint8_t* u,
+                    uint8_t* bits, void* stream);
+int esn_qam_llr(int n_frames, int n_sub, int n_t, int bits_per_sym, const double* X_hat,
+                double* llr, double* sigma2, void* stream);
+int esn_ldpc_decode_count(int n_cw, int n, int k, int m_checks, int n_edges,
+                          const int* chk_ptr, const int* edge_var, const int* var_ptr, const int* var_edge,
+                          const double* y, double snr_db, int maxiter, const uint8_t* u_true, int cw_per_group,
+                          uint8_t* x_out, long long* err_count, long long* bit_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
