@@ -302,3 +302,44 @@ class DetectorSweep:
         reduce_counters(counters, dist, self.world)
         c = counters.cpu().numpy()
         return c[:, 0] / np.maximum(c[:, 1], 1), c
+
+
+def coded_ber_point(sweep, code, ebno_db, snr_idx, n_blocks, frames_per_block=None, cal_frac=0.3, seed=0):
+    """One Eb/No point of the reference's coded + uncoded comparison, batched on the device
+    (Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:283-530): LDPC-coded payloads on every data symbol, ESN and
+    LS/MMSE detection, max-log LLRs, logistic LLR calibration fitted on the first `cal_frac` of the
+    blocks (the reference: the first 30 % of the symbols, :266,:476-482,:513-523) and sum-product
+    decoding of the rest.  Returns dict(ESN_uncoded, MMSE_uncoded, ESN_coded, MMSE_coded, a_esn, ...)."""
+    torch, p, src = sweep.torch, sweep.p, sweep.src
+    F = frames_per_block or p.coherence_symbols
+    G = n_blocks
+    gen = torch.Generator(device=sweep.device)
+    gen.manual_seed((seed * 1000003 + snr_idx * 7919 + 12345) % (2 ** 63 - 1))
+    u = torch.randint(0, 2, (G * F, p.n_t, code.k), generator=gen, device=sweep.device, dtype=torch.uint8)
+    tx_bits = code.encode(u, p.n_t)                                          # [B, N*m, n_t]
+    taps = src.taps(G, snr_idx, 0)
+    pbits, px, py = src.frames(taps, 1, ebno_db, snr_idx, 0, 0, want_x=True)
+    _, _, py_ls = src.frames(taps, 1, ebno_db, snr_idx, 0, 0, ls_pattern=True)
+    _, _, dy = src.frames(taps, F, ebno_db, snr_idx, 0, 1, bits_in=tx_bits)
+    # ESN
+    sweep.set_snr(ebno_db, G)
+    E = sweep.train(py, px, seed=seed + snr_idx)
+    sweep.repair_fit(E)
+    U = _view_real(dy)
+    y = sweep.bank.predict(U, F, T=p.t_frame + p.delay, transient=p.delay + p.cp, precision=sweep.precision,
+                           noise_mode="counter", seed=seed + snr_idx)
+    e_esn, n_esn, xh = sweep.bank.detect_count(y, tx_bits, sweep.p_i, F, p.n_sub, p.n_t, p.m, want_xhat=True)
+    x_esn = torch.view_as_complex(xh.view(G * F, p.n_sub, p.n_t, 2).contiguous())
+    # LS/MMSE baseline
+    H = src.estimate_channel(pbits, py_ls, ebno_db)
+    e_mm, n_mm, x_mm = src.mmse_detect_count(H, dy, tx_bits, F, ebno_db, want_xhat=True)
+    out = dict(ESN_uncoded=float(e_esn.sum()) / float(n_esn.sum()), MMSE_uncoded=float(e_mm.sum()) / float(n_mm.sum()))
+    n_cal = max(1, int(round(cal_frac * G))) * F                             # frames used for calibration
+    for name, xhat in (("ESN", x_esn), ("MMSE", x_mm)):
+        llr, _ = code.llrs(xhat, p.m)
+        a, b = code.fit_calibration(llr[:n_cal], tx_bits[:n_cal], p.m)
+        err, nb = code.decode_count(llr[n_cal:].contiguous(), a, b, u[n_cal:], p.n_t * F, p.m)
+        out[name + "_coded"] = float(err.sum()) / max(float(nb.sum()), 1.0)
+        out["a_" + name.lower()] = a.cpu().numpy()
+        out["b_" + name.lower()] = b.cpu().numpy()
+    return out

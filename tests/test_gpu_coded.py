@@ -86,3 +86,40 @@ def test_sum_product_decoder_matches_oracle(code):
     assert np.abs(got_err - want_err).max() <= 0.02 * code.k * 4              # non-converged words may differ in a few bits
     np.testing.assert_array_equal(nb.cpu().numpy(), [4 * code.k] * (n_cw // 4))
     assert 6 <= conv.sum() < n_cw                                             # the test exercises both regimes
+
+
+def test_gpu_coded_sweep_reproduces_published_columns():
+    """Whole coded comparison on the GPU at the reference's published configuration against ALL FOUR
+    columns of results_ber.csv and the published LLR-calibration slopes
+    (results/results_4x8_cdl_coded_uncoded/LLR_calibration_params_EbNo{0,12,30}dB.txt, bit 0:
+    a_esn / a_mmse = -0.2670/-0.0701, -0.2921/-0.6787, -0.4254/-1.2476).  The published run has 14
+    channel draws per point and its own random code, so the bars are bands, widest in the MMSE
+    waterfall where the coded BER changes by 10x per 3 dB."""
+    from esn_ofdm_mimo_amd.coded import LdpcCode
+    from esn_ofdm_mimo_amd.montecarlo import DetectorSweep, LinkParams, coded_ber_point
+    prm = LinkParams()
+    sw = DetectorSweep(prm, n_reservoir=300, noise=0.001, seed=7, precision="f16", fit_precision="f16",
+                       reservoirs="per_block", pool=16)
+    code = LdpcCode(prm.n_sub * prm.m, 4, 8, seed=11)
+    pub = {0: (0.39036, 0.31962, 0.39209, 0.31793), 6: (0.32307, 0.18538, 0.31658, 0.17010),
+           12: (0.24451, 0.07861, 0.24670, 0.006145), 18: (0.18600, 0.03449, 0.18246, 0.0),
+           30: (0.15690, 0.01892, 0.12669, 0.0)}
+    pub_a = {0: (-0.2670, -0.0701), 12: (-0.2921, -0.6787), 30: (-0.4254, -1.2476)}
+    for si, ebno in enumerate(sorted(pub)):
+        r = coded_ber_point(sw, code, float(ebno), si, 192, seed=3)
+        e_u, m_u, e_c, m_c = pub[ebno]
+        print(f"Eb/No {ebno:2d}: ESN {r['ESN_uncoded']:.4f}/{r['ESN_coded']:.4f} (pub {e_u:.4f}/{e_c:.4f})  "
+              f"MMSE {r['MMSE_uncoded']:.4f}/{r['MMSE_coded']:.5f} (pub {m_u:.4f}/{m_c:.5f})  "
+              f"a0 {r['a_esn'][0]:+.3f}/{r['a_mmse'][0]:+.3f}")
+        assert 0.9 * e_u < r["ESN_uncoded"] < 1.1 * e_u
+        assert 0.9 * m_u < r["MMSE_uncoded"] < 1.1 * m_u
+        assert 0.88 * e_c < r["ESN_coded"] < 1.12 * e_c
+        if m_c > 0.01:
+            assert 0.85 * m_c < r["MMSE_coded"] < 1.15 * m_c
+        elif m_c > 0:
+            assert 0.3 * m_c < r["MMSE_coded"] < 3.0 * m_c          # waterfall: 10x per 3 dB
+        else:
+            assert r["MMSE_coded"] < 1e-4
+        if ebno in pub_a:
+            assert abs(r["a_esn"][0] - pub_a[ebno][0]) < 0.08
+            assert abs(r["a_mmse"][0] - pub_a[ebno][1]) < 0.08

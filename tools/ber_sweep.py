@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--precision", default="f16")
     ap.add_argument("--reservoirs", default="shared", choices=["shared", "per_block"])
     ap.add_argument("--out", default=None)
+    ap.add_argument("--coded", action="store_true", help="add the LDPC-coded columns (SURVEY row f-4)")
     a = ap.parse_args()
     import torch
     from esn_ofdm_mimo_amd.montecarlo import DetectorSweep, LinkParams
@@ -36,8 +37,27 @@ def main():
     fitp = a.precision if a.precision in ("f16", "bf16") else "f32"
     sw = DetectorSweep(prm, n_reservoir=a.n_res, noise=0.001, seed=7, precision=a.precision, fit_precision=fitp,
                        reservoirs=a.reservoirs, pool=16)
-    lines = ["EbNo(dB),ESN_uncoded,MMSE_uncoded"]
     t0 = time.perf_counter()
+    if a.coded:
+        from esn_ofdm_mimo_amd.coded import LdpcCode
+        from esn_ofdm_mimo_amd.montecarlo import coded_ber_point
+        pub_coded = {0: (0.39209, 0.31793), 3: (0.35876, 0.25365), 6: (0.31658, 0.17010), 9: (0.27584, 0.07085),
+                     12: (0.24670, 0.006145), 15: (0.20165, 0.000163), 18: (0.18246, 0.0), 21: (0.15071, 0.0),
+                     24: (0.14270, 0.0), 27: (0.13496, 0.0), 30: (0.12669, 0.0)}
+        code = LdpcCode(prm.n_sub * prm.m, 4, 8, seed=11)
+        print(f"[LDPC] regular code: n={code.n}, k={code.k}, rate={code.k / code.n:.3f}")
+        lines = ["EbNo(dB),ESN_uncoded,MMSE_uncoded,ESN_coded,MMSE_coded"]      # the reference's header (:639)
+        for si, ebno in enumerate(sorted(PUBLISHED)):
+            r = coded_ber_point(sw, code, float(ebno), si, a.blocks, F, seed=7)
+            lines.append(f"{ebno},{r['ESN_uncoded']},{r['MMSE_uncoded']},{r['ESN_coded']},{r['MMSE_coded']}")
+            print(f"Eb/No {ebno:2d} dB  ESN {r['ESN_uncoded']:.5f}/{r['ESN_coded']:.5f} (pub {PUBLISHED[ebno][0]:.5f}/"
+                  f"{pub_coded[ebno][0]:.5f})   MMSE {r['MMSE_uncoded']:.5f}/{r['MMSE_coded']:.6f} "
+                  f"(pub {PUBLISHED[ebno][1]:.5f}/{pub_coded[ebno][1]:.6f})   a_mmse[0] {r['a_mmse'][0]:+.3f}", flush=True)
+        print(f"{len(PUBLISHED)} coded points in {time.perf_counter() - t0:.1f} s")
+        if a.out:
+            open(a.out, "w").write("\n".join(lines) + "\n")
+        return
+    lines = ["EbNo(dB),ESN_uncoded,MMSE_uncoded"]
     for si, ebno in enumerate(sorted(PUBLISHED)):
         d = sw.src.blocks_fast(float(ebno), si, 0, a.blocks, F, with_ls_pilot=True)
         sw.set_snr(float(ebno), a.blocks)
