@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libesn_hip.so")
+LIB_PATH = os.environ.get("ESN_HIP_LIB") or os.path.join(_PKG, "libesn_hip.so")   # env: tuning builds only
 
 F64, F32, F16, BF16 = 0, 1, 2, 3
 PRECISIONS = {"f64": F64, "f32": F32, "f16": F16, "bf16": BF16}

@@ -43,7 +43,8 @@ def _build(LIB, bdir, extra, verbose):
     for src in SOURCES:
         obj = os.path.join(PKG, bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        per_file = os.environ.get("ESN_FLAGS_" + src.replace(".hip", "").upper(), "").split()
+        cmd = [hipcc, *FLAGS, *extra, *per_file, "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, pr in procs:
         out, _ = pr.communicate()
@@ -58,4 +59,9 @@ def _build(LIB, bdir, extra, verbose):
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, stamps="--stamps" in sys.argv))
+    if "--variant" in sys.argv:     # tuning builds: libesn_hip_<name>.so with ESN_EXTRA_FLAGS (load via ESN_HIP_LIB)
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(_build(os.path.join(PKG, f"libesn_hip_{name}.so"), "build_" + name,
+                     os.environ.get("ESN_EXTRA_FLAGS", "").split(), True))
+    else:
+        print(build_library(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

@@ -21,6 +21,7 @@ struct Geometry {
     int NW, MT, NT;  // waves, row tiles / wave, column tiles / wave (MFMA kernels)
     int ro_parts;    // readout images per group: 1, or 2 (hi + lo) for fp16/bf16 with n_out > 8
     int ro_fold;     // fp16/bf16, n_out <= 8: rows 0-7 = hi, rows 8-15 = lo of ONE 16-row image
+    int skew;        // predict: the two waves of a SIMD run one third of a step apart (esn_recur_mfma_impl.h)
 };
 
 struct RecurParams {

@@ -50,9 +50,20 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
     g->Bt = 32 * NT;
     g->ro_fold = (es == 2 && n_out <= 8) ? 1 : 0;
     g->ro_parts = (es == 2 && !g->ro_fold) ? 2 : 1;
+    // skewed wave schedule (predict): 8-wave fp16/bf16 tilings with one readout image and state
+    // k-groups that split into two even halves; ESN_SKEW=0 keeps the in-step schedule (A/B runs)
+    {
+        const char* sk = getenv("ESN_SKEW");
+        const int nkgS = g->Mp * es / 32;
+        const int n_uf = g->Kp * es / 32 - nkgS;
+        g->skew = (!harvest && es == 2 && NW == 8 && NT >= 2 && g->ro_parts == 1 && nkgS % 8 == 0 && n_uf <= 4 &&
+                   (n_in == 2 || n_in == 4 || n_in == 8 || n_in == 16) &&
+                   !(sk && sk[0] == '0')) ? 1 : 0;
+    }
     // Zt image + the small frame / scale tables behind it (esn_recur_mfma_impl.h)
     const size_t tables = 4 * (size_t)g->Bt + 8 * (size_t)(g->Bt / 16) * ((g->kfb - g->kin) + 16)
-                          + 8 * (size_t)g->Bt * n_in;     // + raw input rows of the next step (LDS-DMA)
+                          + 8 * (size_t)g->Bt * n_in      // + raw input rows of the next step (LDS-DMA)
+                          + 4 * (size_t)g->Bt;            // + input offsets of the frames (skewed schedule)
     return (size_t)g->Bt * g->Ks * es + tables <= 160 * 1024;
 }
 

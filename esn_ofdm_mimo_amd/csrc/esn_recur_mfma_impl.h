@@ -25,6 +25,7 @@
 // 1 x v_mfma_f32_32x32x16_{f16,bf16}.  (The k order inside a group is a fixed
 // permutation applied to both operands, which a dot product does not see.)
 #pragma once
+#include <type_traits>
 #include "esn_common.h"
 
 namespace esn {
@@ -110,7 +111,7 @@ struct TraitsBF16 {
     static __device__ __forceinline__ float act(float z) { return tanh_prescaled(z); }   // weights carry 2 log2 e
 };
 
-template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE>
+template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE, bool SKEW>
 __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     extern __shared__ __attribute__((aligned(16))) char zt[];   // Zt[Bt][Ks] elements, then tables
     constexpr int ES = TR::ES;
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     float2* tab_un = tab_in + NOWN * kin_p;
     // raw float64 input rows of the NEXT step, filled by LDS-DMA (no VGPRs): [NOWN][16][n_in]
     double* in_raw = reinterpret_cast<double*>(tab_un + NOWN * 16);
+    // skewed schedule: byte offset of each frame's input block from the tile's base frame (-1 = padding slot)
+    int* tab_off = reinterpret_cast<int*>(in_raw + (size_t)BT * n_in);
     for (int i = tid; i < BT; i += NTHREADS) { int gtmp; tab_fr[i] = slot_frame(p, slot0 + i, gtmp); }
     for (int i = tid; i < NOWN * kin_p; i += NTHREADS) {
         const int c16 = i / kin_p, c = i % kin_p;
@@ -395,6 +398,340 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 #pragma unroll
     for (int i = 0; i < OC; ++i) any_ro = any_ro || (wop[i] != nullptr);
 
+    if constexpr (SKEW) {
+        // ================= skewed schedule (predict) ==================================
+        // The in-step schedule below serialises MFMA work (G) and VALU work (E) behind barriers.
+        // Here the waves form two sets, A = waves [0, NW/2) owning rows / state k-groups of the
+        // lower half and B = the upper half, one wave of each per SIMD.  Every wave walks the same
+        // cyclic program  P0: k-groups of half A | P1: k-groups of half B | P2: [U;F] groups + E
+        // with a barrier after each phase, set B one phase behind set A:
+        //     slot 3s   : A P0(s) reads X_A(s)            B P2(s-1) writes X_B(s)
+        //     slot 3s+1 : A P1(s) reads X_B(s)            B P0(s)   reads X_A(s)     + readout Y_s -> F_s
+        //     slot 3s+2 : A P2(s) writes X_A(s+1)         B P1(s)   reads X_B(s)     + yU_s
+        // so the activation of one wave runs beside the MFMAs of the other wave of its SIMD, the
+        // state stays single-buffered and the weights are still streamed once per step.  Every
+        // accumulator sums the k-groups in the same order as the in-step schedule.
+        static_assert(!HARVEST && OC == 1 && NW % 2 == 0, "skewed schedule: predict, one column tile per wave");
+        const int lag = wave >= NW / 2 ? 1 : 0;
+        const int nkgH = nkgS / 2;               // k-groups per half (multiple of 4: mfma_geometry)
+        const int nk64H = nk64S / 2;             // == trips per half == readout groups per half
+        const int n_uf = nkg - nkgS;             // [U;F] k-groups, <= 4
+        f32x16 acc[MT][NT];
+        u32x4 abuf[4][MT], bA[NT], ra[4];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+        };
+        // Weight streams by buffer loads: one descriptor per stream, the per-lane part (lane*16) in
+        // one VGPR, the fragment offset in an SGPR -- no per-load 64-bit address arithmetic.
+        // A fragments: FOUR k-groups in flight per wave.  Buffer j holds k-groups = j (mod 4) and is
+        // refilled with the group four ahead right after its last MFMA.  (A rotating register
+        // pipeline does not survive the compiler: it re-times the loads to "when the register
+        // frees", about one k-group of look-ahead, and an L2 hit costs 1-2k cycles under this load.)
+        // Nothing in the GEMM code is conditional: a branch around a load makes the compiler fall
+        // back to s_waitcnt vmcnt(0) at the loop head, and a branch around MFMAs makes it shuffle
+        // the accumulators between the arms.  A load that must not happen gets the per-lane offset
+        // OOB (>= the descriptor's num_records): the buffer unit returns zeros without touching
+        // memory, and zero fragments leave the accumulators unchanged.
+        const int lane16 = lane * 16;
+        constexpr int OOB = 0x7ffffff0;
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride), 0,
+            (int)p.wset_stride, 0x00020000);
+        const int w_row0 = wave * MT * nkg;
+        auto loadA = [&](u32x4 (&a)[MT], int kg) {       // kg >= nkg: no load, zeros
+            const bool live = kg < nkg;
+            const int voff = live ? lane16 : OOB;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    w_rsrc, voff, live ? (w_row0 + mt * nkg + kg) * 1024 : 0, 0));
+        };
+        auto loadB = [&](u32x4 (&b)[NT], int kg) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + kg * 32);
+        };
+        auto mma_all = [&](const u32x4 (&a)[MT], const u32x4 (&b)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) TR::mma32(acc[mt][nt], a[mt], b[nt]);
+        };
+        // W_out fragments of the owned column tile, two trips ahead: ra[2i], ra[2i+1] = 64-byte
+        // groups t and t + nk64H of the trips t = i (mod 2); `on` false: zeros, no traffic
+        const int own_grp = __builtin_amdgcn_readfirstlane((slot0 + wave * 16) / p.Fpad);
+        const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.packed_wout)
+                              + (size_t)(own_grp < p.n_groups ? own_grp : 0) * p.wout_stride),
+            0, (int)p.wout_stride, 0x00020000);
+        auto load_ra = [&](int i, int t, bool on) {
+            on = on && t < nk64H;
+            const int voff = on ? lane16 : OOB;
+            ra[2 * i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wo_rsrc, voff, on ? t * 1024 : 0, 0));
+            ra[2 * i + 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wo_rsrc, voff, on ? (t + nk64H) * 1024 : 0, 0));
+        };
+        auto ro_prefetch = [&](bool on) { load_ra(0, 0, on); load_ra(1, 1, on); };
+        // State k-groups [kg0, kg0 + nkgH) out of abuf, four per trip of the loop; abuf[j] holds group
+        // kg0 + j on entry and kg0 + nkgH + j on exit (past the last [U;F] group: zeros -- the next
+        // step's first groups are fetched half-way through phase E, when half of the accumulators
+        // have been retired).  The readout of the owned column tile rides along, 64-byte groups t
+        // and t + nk64H in trip t; in the slots where this wave does not read out, ra[] is zero.
+        auto gemm_half = [&](int kg0, bool ro_on) {
+            loadB(bA, kg0);
+            u32x4 rb0, rb1;
+            for (int i = 0; i < nkgH; i += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kg = kg0 + i + j;
+                    const int t = (i + j) >> 1;
+                    mma_all(abuf[j], bA);
+                    if (j % 2 == 1) { TR::mma16(yacc[0], ra[j - 1], rb0); TR::mma16(yacc[0], ra[j], rb1); }
+                    // Two pinned regions per k-group.  The loads may not move above the MFMAs: the
+                    // scheduler would give them new registers (A: eight live buffers instead of four;
+                    // B: double-buffered) and the kernel no longer fits 256 VGPRs.  The B fragments
+                    // are therefore single-buffered -- their LDS latency is covered by the other wave
+                    // of the SIMD when both run MFMAs, and hidden behind E otherwise.
+                    __builtin_amdgcn_sched_barrier(0);
+                    loadA(abuf[j], kg + 4);
+                    loadB(bA, kg + 1);
+                    if (j % 2 == 0) {
+                        rb0 = *reinterpret_cast<const u32x4*>(zrow0 + t * 64);
+                        rb1 = *reinterpret_cast<const u32x4*>(zrow0 + (t + nk64H) * 64);
+                    } else {
+                        load_ra(j >> 1, t + 2, ro_on);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        auto uf_groups = [&]() {
+            loadB(bA, nkgS);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < n_uf) {
+                    mma_all(abuf[j], bA);
+                    if (j + 1 < n_uf) loadB(bA, nkgS + j + 1);
+                }
+            }
+        };
+        auto next_step_A = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) loadA(abuf[j], j);
+        };
+        // E for column tiles [NT0, NT1).  fp16 + counter noise takes a packed-half tail: the four noise
+        // bytes of a quad become two pairs of halves 1024 + byte (one v_perm_b32 each, exponent byte
+        // 0x64), and   x = tanh + noise ((byte + 1/2)/256 - 1/2)   is one v_pk_fma_f16 per pair,
+        //   x = (1024 + byte) c1 + t,   t = half(1 - 2/(1 + 2^z) + c0 - 1024 c1),  c1 = noise/256
+        // instead of four conversions, four adds and four fmas in float32.
+        constexpr bool PK_NOISE = NOISE == ESN_NOISE_COUNTER && std::is_same<TR, TraitsF16>::value;
+        const float t_bias = 1.0f + n_c0 - 1024.0f * n_c1;
+        typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const h16x2 c1h = {(_Float16)n_c1, (_Float16)n_c1};
+        auto activate = [&](int s, auto nt0_tag, auto nt1_tag, const int (&frs)[NT / 2]) {
+            constexpr int NT0 = decltype(nt0_tag)::value, NT1 = decltype(nt1_tag)::value;
+#pragma unroll
+            for (int nt = NT0; nt < NT1; ++nt) {
+                const int col = nt * 32 + r;
+                const int fr = frs[nt - NT0];
+                uint32_t key = 0;
+                const double* nz = nullptr;
+                if (NOISE == ESN_NOISE_COUNTER)
+                    key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
+                if (NOISE == ESN_NOISE_TENSOR && fr >= 0)
+                    nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = (wave * MT + mt) * 32 + 8 * q + 4 * h;
+                        char* dst = zt + (size_t)col * row_bytes + (size_t)row * ES;
+                        if constexpr (PK_NOISE) {
+                            float t[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float e = __builtin_amdgcn_exp2f(acc[mt][nt][4 * q + j]);
+                                t[j] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), t_bias);
+                            }
+                            uint32_t sq = key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U;    // noise_quad
+                            sq ^= sq << 13; sq ^= sq >> 17; sq ^= sq << 5;
+                            sq += sq << 3; sq ^= sq >> 11;
+                            const h16x2 w01 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, sq, 0x04010400u));
+                            const h16x2 w23 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, sq, 0x04030402u));
+                            const h16x2 t01 = __builtin_convertvector(f32x2{t[0], t[1]}, h16x2);
+                            const h16x2 t23 = __builtin_convertvector(f32x2{t[2], t[3]}, h16x2);
+                            const h16x2 x01 = __builtin_elementwise_fma(w01, c1h, t01);
+                            const h16x2 x23 = __builtin_elementwise_fma(w23, c1h, t23);
+                            *reinterpret_cast<u32x2*>(dst) =
+                                u32x2{__builtin_bit_cast(uint32_t, x01), __builtin_bit_cast(uint32_t, x23)};
+                        } else {
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[mt][nt][4 * q + j]);
+                            if (NOISE == ESN_NOISE_COUNTER) {
+                                uint32_t sq = key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U;
+                                sq ^= sq << 13; sq ^= sq >> 17; sq ^= sq << 5;
+                                sq += sq << 3; sq ^= sq >> 11;
+                                v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
+                                v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
+                                v[2] = fmaf((float)((sq >> 16) & 0xffU), n_c1, v[2] + n_c0);
+                                v[3] = fmaf((float)(sq >> 24), n_c1, v[3] + n_c0);
+                            } else if (NOISE == ESN_NOISE_TENSOR) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+                            }
+                            TR::store4(dst, v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        const std::integral_constant<int, 0> nt_lo;
+        const std::integral_constant<int, NT / 2> nt_mid;
+        const std::integral_constant<int, NT> nt_hi;
+        // Inputs: set B stages them for all column tiles (wave w: tiles 2(w - NW/2), +1).  The raw
+        // float64 rows of step s+1 go HBM -> LDS staging area by LDS-DMA at the very end of phase
+        // E of step s (slot 3s+3) and are converted into the U columns of Zt at the start of
+        // P0(s+1) (slot 3s+4), the one slot in which nobody reads U.  Placement matters twice:
+        // with a DMA pending the compiler puts s_waitcnt vmcnt(0) in front of the next LDS read
+        // (so the DMA must not precede a GEMM loop), and staging through VGPRs instead ends in
+        // scratch spills that wait for every HBM load in turn.
+        const int in_c0 = 2 * (wave - NW / 2);
+        const int lcpf = __builtin_ctz(cpf), lkin = __builtin_ctz(kin_p);     // powers of two (mfma_geometry)
+        const size_t in_frame_bytes = (size_t)in_stride * 8;
+        const size_t u_base_frame = (size_t)grp0 * p.F;                       // first frame of the tile's first group
+        for (int i = tid; i < BT; i += NTHREADS) {
+            const int fr = tab_fr[i];
+            tab_off[i] = fr >= 0 ? (int)(((size_t)fr - u_base_frame) * in_frame_bytes) : -1;
+        }
+        __syncthreads();
+        const size_t u_left = ((size_t)p.n_frames - u_base_frame) * in_frame_bytes;
+        const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.U) + u_base_frame * in_frame_bytes), 0,
+            (int)(u_left < 0x7fffffffu ? u_left : 0x7fffffffu), 0x00020000);
+        auto dma_inputs_b = [&](int s) {
+            const int row = s + p.in_row_off;
+            const bool row_ok = row < p.T_in;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int c = in_c0 + ti;
+                for (int e0 = 0; e0 < 16 * cpf; e0 += 64) {          // wave-uniform trip count
+                    const int e = e0 + lane;
+                    const int off = (e < 16 * cpf) ? tab_off[c * 16 + (e >> lcpf)] : -1;
+                    // padding frames and rows past T_in: offset out of range, nothing is fetched
+                    const int voff = (off >= 0 && row_ok) ? off + ((e & (cpf - 1)) << 4) : OOB;
+                    char* dst = reinterpret_cast<char*>(in_raw + (size_t)c * 16 * n_in) + (size_t)e0 * 16;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
+                                                         voff, row_ok ? row * n_in * 8 : 0, 0, 0);
+                }
+            }
+        };
+        auto commit_inputs_b = [&](int s) {
+            const bool row_ok = s + p.in_row_off < p.T_in;     // (an out-of-range DMA leaves LDS untouched)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int c = in_c0 + ti;
+                for (int e = lane; e < 16 * kin_p; e += 64) {
+                    const int f = e >> lkin, ci = e & (kin_p - 1);
+                    float v = 0.f;
+                    if (tab_fr[c * 16 + f] >= 0 && ci < n_in) {
+                        const float2 ss = tab_in[c * kin_p + ci];
+                        const double raw = row_ok ? in_raw[((size_t)c * 16 + f) * n_in + ci] : 0.0;
+                        v = fmaf((float)raw, ss.x, ss.y);
+                    }
+                    TR::store1(zt + (size_t)(c * 16 + f) * row_bytes + (size_t)(g.kin + ci) * ES, v);
+                }
+            }
+        };
+#ifdef ESN_STAMPS
+        unsigned long long sk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ESN_SK_ADD(i, a, b) sk_acc[i] += (b) - (a);
+#else
+#define ESN_SK_ADD(i, a, b)
+#endif
+        // One program for both sets.  The readout runs in slot 3s+1 (P1 of set A, P0 of set B) and
+        // yU_s in slot 3s+2 (P2 of set A, P1 of set B).
+        const bool has_ro = __builtin_amdgcn_readfirstlane(wop[0] != nullptr ? 1 : 0) != 0;   // provably wave-uniform
+        next_step_A();
+        ro_prefetch(false);
+        if (lag) __syncthreads();                                      // slot 0: set A alone
+        for (int s = 0; s < p.S; ++s) {
+            const bool ro = has_ro && s > 0;
+            ESN_STAMP(t0)
+            zero_acc();
+            if (lag && s > 0) commit_inputs_b(s);                     // ---- P0
+            gemm_half(0, ro && lag);
+            if (lag) { if (ro) finish_readout(s - 1 - p.transient, true); }
+            ro_prefetch(ro && !lag);                                   // set A: for P1, in flight over the barrier
+            ESN_STAMP(t1)
+            __syncthreads();
+            ESN_STAMP(t2)
+            gemm_half(nkgH, ro && !lag);                               // ---- P1
+            if (!lag) { if (ro) finish_readout(s - 1 - p.transient, true); }
+            ESN_STAMP(t3)
+            __syncthreads();
+            ESN_STAMP(t4)
+            // ---- P2.  The VALU-bound wave gets the issue slots: its SIMD partner is in an MFMA
+            // phase with slack (and, for set B, would otherwise win every arbitration by age)
+            __builtin_amdgcn_s_setprio(2);
+            const u32x4 ra_u = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wo_rsrc, has_ro ? lane16 : OOB, has_ro ? nk64S * 1024 : 0, 0));
+            int frs[NT / 2];
+#pragma unroll
+            for (int i = 0; i < NT / 2; ++i) frs[i] = tab_fr[i * 32 + r];
+            uf_groups();
+            ESN_STAMP(u1)
+            activate(s, nt_lo, nt_mid, frs);
+            ESN_STAMP(u2)
+            {   // yU_s = Wout[:, inputs] U_s (the feedback columns of that group carry zero weights);
+                // U_s stays in Zt until set B commits U_{s+1} at the start of slot 3s+4
+                const u32x4 rb_u = *reinterpret_cast<const u32x4*>(zrow0 + nk64S * 64);
+                TR::mma16(yacc[0], ra_u, rb_u);
+            }
+            next_step_A();
+            ro_prefetch(lag && has_ro && s + 1 < p.S);                 // set B: for P0(s+1)
+#pragma unroll
+            for (int i = 0; i < NT / 2; ++i) frs[i] = tab_fr[(NT / 2 + i) * 32 + r];
+            ESN_STAMP(u3)
+            // last LDS read of the phase is behind us: the input DMA of step s+1 flies during the rest of E
+            if (lag && s + 1 < p.S) dma_inputs_b(s + 1);
+            ESN_STAMP(u4)
+            activate(s, nt_mid, nt_hi, frs);
+            ESN_STAMP(u5)
+            __builtin_amdgcn_s_setprio(0);
+            ESN_STAMP(t5)
+            __syncthreads();
+            ESN_STAMP(t6)
+            ESN_SK_ADD(0, t0, t1) ESN_SK_ADD(1, t1, t2) ESN_SK_ADD(2, t2, t3)
+            ESN_SK_ADD(3, t3, t4) ESN_SK_ADD(4, t4, t5) ESN_SK_ADD(5, t5, t6)
+            ESN_SK_ADD(6, t4, u1) ESN_SK_ADD(7, u1, u2) ESN_SK_ADD(8, u2, u3) ESN_SK_ADD(9, u3, u4)
+            ESN_SK_ADD(10, u4, u5) ESN_SK_ADD(11, u5, t5)
+        }
+        if (!lag) __syncthreads();                                     // slot 3S: set B finishes X_B(S)
+#undef ESN_SK_ADD
+        if (any_ro) {                                                  // Y_S = yU_{S-1} + Wout_x X_S
+            readout_groups(0, nk64S);
+            finish_readout(p.S - 1 - p.transient, false);
+        }
+#ifdef ESN_STAMPS
+        if (p.stamps && blockIdx.x == 0 && lane == 0) {
+            for (int i = 0; i < 6; ++i) p.stamps[wave * 8 + i] = sk_acc[i];
+            for (int i = 0; i < 6; ++i) p.stamps[(8 + wave) * 8 + i] = sk_acc[6 + i];    // inside P2
+            p.stamps[wave * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);   // HW_ID
+        }
+#endif
+        return;
+    }
+
 #ifdef ESN_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -583,30 +920,34 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 
 // ---- host side: geometry choice and launch -------------------------------------
 
-template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE>
+template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE, bool SKEW = false>
 static int launch_k(const RecurParams& p, hipStream_t stream) {
     const int kin_p = p.g.kfb - p.g.kin, nown = p.g.Bt / 16;
     size_t lds = (size_t)p.g.Bt * p.g.Ks * TR::ES + 4 * (size_t)p.g.Bt + 8 * (size_t)nown * (kin_p + 16)
-                 + 8 * (size_t)p.g.Bt * p.n_in;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE>),
+                 + 8 * (size_t)p.g.Bt * p.n_in + 4 * (size_t)p.g.Bt;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE, SKEW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE>), dim3(p.n_tiles), dim3(NW * 64), lds,
+    hipLaunchKernelGGL((recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE, SKEW>), dim3(p.n_tiles), dim3(NW * 64), lds,
                        stream, p);
     return (int)hipGetLastError();
 }
 
-template <typename TR, int NW, int MT, int NT, bool HARVEST>
+template <typename TR, int NW, int MT, int NT, bool HARVEST, bool SKEW = false>
 static int launch_n(const RecurParams& p, hipStream_t stream) {
     switch (p.noise_mode) {
-        case ESN_NOISE_NONE: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_NONE>(p, stream);
-        case ESN_NOISE_TENSOR: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_TENSOR>(p, stream);
-        default: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_COUNTER>(p, stream);
+        case ESN_NOISE_NONE: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_NONE, SKEW>(p, stream);
+        case ESN_NOISE_TENSOR: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_TENSOR, SKEW>(p, stream);
+        default: return launch_k<TR, NW, MT, NT, HARVEST, ESN_NOISE_COUNTER, SKEW>(p, stream);
     }
 }
 
 template <typename TR, int NW, int MT, int NT>
 static int launch_one(const RecurParams& p, hipStream_t stream) {
+    // skewed schedule: instantiated for the 8-wave fp16 / bf16 predict tilings (mfma_geometry sets g.skew)
+    if constexpr (NW == 8 && TR::ES == 2 && NT >= 2) {
+        if (!p.harvest && p.g.skew) return launch_n<TR, NW, MT, NT, false, true>(p, stream);
+    }
     return p.harvest ? launch_n<TR, NW, MT, NT, true>(p, stream) : launch_n<TR, NW, MT, NT, false>(p, stream);
 }
 

@@ -36,10 +36,19 @@ T = params.t_frame + params.delay
 for _ in range(2):
     sweep.bank.predict(U, F, T=T, transient=params.delay + params.cp, precision=prec, noise_mode="counter", seed=3)
 torch.cuda.synchronize()
-st = buf.cpu().numpy().reshape(16, 8)[:8, :6].astype(float) / T
+raw = buf.cpu().numpy().reshape(16, 8)
+hw = raw[:8, 6]
+print("HW_ID per wave: " + " ".join(f"w{w}:simd{(int(v) >> 4) & 3}/cu{(int(v) >> 8) & 15}" for w, v in enumerate(hw)))
+st = raw[:8, :6].astype(float) / T
 names = ["G1 gemm+ro", "wait Ba", "G2 in+fb", "wait Bb", "E act+noise", "wait Bc"]
 print(f"precision {prec}: cycles per timestep (workgroup 0), per wave")
 print("wave " + " ".join(f"{n:>13s}" for n in names) + "        total")
 for w in range(8):
     print(f"{w:4d} " + " ".join(f"{v:13.0f}" for v in st[w]) + f" {st[w].sum():12.0f}")
 print("mean " + " ".join(f"{v:13.0f}" for v in st.mean(0)) + f" {st.mean(0).sum():12.0f}")
+
+if raw[8:, :6].any():
+    sub = raw[8:16, :6].astype(float) / T
+    print("inside P2 (skewed schedule): uf_groups, E first half, prefetch issue, E second half, yU, input fetch")
+    for w in range(8):
+        print(f"{w:4d} " + " ".join(f"{v:13.0f}" for v in sub[w]))
