@@ -560,9 +560,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                                 const float e = __builtin_amdgcn_exp2f(acc[mt][nt][4 * q + j]);
                                 t[j] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), t_bias);
                             }
-                            uint32_t sq = key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U;    // noise_quad
-                            sq ^= sq << 13; sq ^= sq >> 17; sq ^= sq << 5;
-                            sq += sq << 3; sq ^= sq >> 11;
+                            const uint32_t sq = noise_mix(key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U);
                             const h16x2 w01 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, sq, 0x04010400u));
                             const h16x2 w23 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, sq, 0x04030402u));
                             const h16x2 t01 = __builtin_convertvector(f32x2{t[0], t[1]}, h16x2);
@@ -576,9 +574,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[mt][nt][4 * q + j]);
                             if (NOISE == ESN_NOISE_COUNTER) {
-                                uint32_t sq = key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U;
-                                sq ^= sq << 13; sq ^= sq >> 17; sq ^= sq << 5;
-                                sq += sq << 3; sq ^= sq >> 11;
+                                const uint32_t sq = noise_mix(key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U);
                                 v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
                                 v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
                                 v[2] = fmaf((float)((sq >> 16) & 0xffU), n_c1, v[2] + n_c0);
@@ -668,9 +664,13 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             const bool ro = has_ro && s > 0;
             ESN_STAMP(t0)
             zero_acc();
-            if (lag && s > 0) commit_inputs_b(s);                     // ---- P0
+            // ---- P0.  Set B (the younger wave of each SIMD) would lose every issue arbitration of
+            // slot 3s+1 to set A's P1 and finish its half alone, latency-bound: even them out
+            if (lag) __builtin_amdgcn_s_setprio(1);
+            if (lag && s > 0) commit_inputs_b(s);
             gemm_half(0, ro && lag);
             if (lag) { if (ro) finish_readout(s - 1 - p.transient, true); }
+            if (lag) __builtin_amdgcn_s_setprio(0);
             ro_prefetch(ro && !lag);                                   // set A: for P1, in flight over the barrier
             ESN_STAMP(t1)
             __syncthreads();
@@ -870,9 +870,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     //  noise they pick up is never read -- no masking needed)
                     if (NOISE == ESN_NOISE_COUNTER) {
                         // row/4 = (wave*MT*8 + h) + (mt*8 + 2q): the second term folds at compile time
-                        uint32_t sq = key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U;
-                        sq ^= sq << 13; sq ^= sq >> 17; sq ^= sq << 5;
-                        sq += sq << 3; sq ^= sq >> 11;
+                        const uint32_t sq = noise_mix(key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U);
                         // + noise*((byte+0.5)/256 - 0.5) = byte*n_c1 + n_c0
                         v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
                         v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
