@@ -237,13 +237,32 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     const double* Dg = sp.D + ((size_t)g * sp.T + sp.transient) * nrhs;
     constexpr int AS_LD = CH_NP + 4;
 
-    // ---- phase 1: G = sum_k a_k a_k^T, 4x4 register tile per thread ----------------
-    const int tx = tid & 31, ty = tid >> 5;          // G rows 4*ty.., cols 4*tx..
-    double acc[4][4];
+    // ---- phase 1: G = sum_k a_k a_k^T on the float64 matrix pipe ------------------------------
+    // v_mfma_f64_16x16x4_f64 (A[l%16][l/16], B[l/16][l%16], C reg i: row 4i + l/16, col l%16) runs at
+    // the vector-FMA rate on gfx950 (64 cycles, probe in tools/mfma_layout_probe.hip) but takes
+    // one LDS read per operand and 1024 FMAs, where a 4x4 register tile takes 8 reads per 16 FMAs
+    // per lane -- the old loop was LDS-bound at a tenth of the FMA rate.  Only the 36 lower 16x16
+    // tiles are formed (the factorisation reads nothing above the diagonal), dealt to the 16
+    // waves so that every SIMD (wave % 4) carries 9: waves 0-3 three tiles, the others two.
+    // lower tile t = ti (ti + 1) / 2 + tj goes to SIMD t % 4, slot t / 4 of its nine
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int g_cnt = (wvu >> 2) == 0 ? 3 : 2;
+    int g_ti[3], g_tj[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int q = 0; q < 3; ++q) {
+        const int m = wvu >> 2;
+        const int idx = m == 0 ? q : 2 * m + 1 + (q < 2 ? q : 0);
+        const int t = 4 * idx + (wvu & 3);
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        g_ti[q] = ti;
+        g_tj[q] = t - ti * (ti + 1) / 2;
+    }
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    f64x4 acc[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int q = 0; q < 3; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int fr_off = (lane >> 4) * (CH_NP + 4) + (lane & 15);      // operand element of this lane in a 4-row slab
     // tall case also needs A^T B: thread (o, i) partial sums, o < nrhs, i < n  -> first nrhs*128 threads
     double atb = 0.0;
     const int ao = tid / CH_NP, ai = tid % CH_NP;
@@ -280,18 +299,14 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
         if (more) fetch(k0 + CH_KC);
         const double* Ac = Abuf[cur];
         const int kmax = (m - k0 < CH_KC) ? m - k0 : CH_KC;
-        for (int kk = 0; kk < kmax; ++kk) {
-            const double* row = Ac + kk * AS_LD;
-            double a0 = row[4 * ty], a1 = row[4 * ty + 1], a2 = row[4 * ty + 2], a3 = row[4 * ty + 3];
-            double b0 = row[4 * tx], b1 = row[4 * tx + 1], b2 = row[4 * tx + 2], b3 = row[4 * tx + 3];
-            acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
-            acc[0][2] = fma(a0, b2, acc[0][2]); acc[0][3] = fma(a0, b3, acc[0][3]);
-            acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
-            acc[1][2] = fma(a1, b2, acc[1][2]); acc[1][3] = fma(a1, b3, acc[1][3]);
-            acc[2][0] = fma(a2, b0, acc[2][0]); acc[2][1] = fma(a2, b1, acc[2][1]);
-            acc[2][2] = fma(a2, b2, acc[2][2]); acc[2][3] = fma(a2, b3, acc[2][3]);
-            acc[3][0] = fma(a3, b0, acc[3][0]); acc[3][1] = fma(a3, b1, acc[3][1]);
-            acc[3][2] = fma(a3, b2, acc[3][2]); acc[3][3] = fma(a3, b3, acc[3][3]);
+        // (rows past m and columns past n of the chunk are zero-filled by fetch)
+#pragma unroll 2
+        for (int k4 = 0; k4 < CH_KC; k4 += 4) {
+            const double* slab = Ac + k4 * AS_LD + fr_off;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q < g_cnt)
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(slab[g_ti[q] * 16], slab[g_tj[q] * 16], acc[q], 0, 0, 0);
         }
         if (!wide && ao < nrhs) {
             const double sc = sp.t_scale ? sp.t_scale[(size_t)g * nrhs + ao] : 1.0;
@@ -306,9 +321,12 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     __syncthreads();
     // ---- phase 2: G and the right-hand sides into LDS ----------------------------------
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int q = 0; q < 3; ++q)
+        if (q < g_cnt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Gs[(4 * ty + i) * CH_LD + 4 * tx + j] = acc[i][j];
+            for (int i = 0; i < 4; ++i)
+                Gs[(g_ti[q] * 16 + 4 * i + (lane >> 4)) * CH_LD + g_tj[q] * 16 + (lane & 15)] = acc[q][i];
+        }
     if (tid == 0) sh_bad = 0;
     for (int e = tid; e < nrhs * CH_NP; e += 1024) {
         const int o = e / CH_NP, i = e % CH_NP;
@@ -332,25 +350,100 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     __syncthreads();
     const double piv_tol = fmax(sh_max[0], sh_max[1]) * 1e-14;
 
-    // ---- phase 3: right-looking Cholesky, reduction-free ---------------------------------
-    // column j is snapshotted, then (i) scaled into L[:, j] and (ii) its rank-1 term removed from
-    // the trailing lower triangle, 8 threads per row; 1/L[j][j] is kept for the substitutions
-    __shared__ double sh_col[CH_NP], sh_invd[CH_NP];
-    const int ri = tid >> 3, part = tid & 7;         // row 0..127
-    for (int j = 0; j < ((sp.skip & 2) ? 1 : n); ++j) {
-        if (tid < n) sh_col[tid] = (tid >= j) ? Gs[tid * CH_LD + j] : 0.0;
+    // ---- phase 3: blocked right-looking Cholesky, 16-column blocks --------------------------
+    // per block: (a) wave 0 factorises the 16x16 diagonal block in registers (lane r = row r, the
+    // pivots travel by v_readlane) and inverts it (lane c = column c of L11^-1); (b) the panel
+    // L21 = A21 L11^-T and (c) the trailing update A22 -= L21 L21^T are 16x16x4 float64 MFMAs out
+    // of / into the LDS image.  Three barriers per 16 columns instead of two per column.
+    // A rejected pivot (v <= tol) drops its direction, as pinv would: unit diagonal, zero column
+    // (row c of L11^-1 is zeroed so the panel column vanishes too) and the group is flagged.
+    __shared__ double sh_invd[CH_NP];
+    __shared__ double sh_linv[16][17];
+    auto bcast = [](double x, int src) -> double {       // wave-uniform copy of lane `src` (constant)
+        const uint64_t u = __builtin_bit_cast(uint64_t, x);
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, src);
+        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), src);
+        return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    };
+    const int nblk = (sp.skip & 2) ? 1 : (n + 15) / 16;
+    const int lr = lane & 15, lq = lane >> 4;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int j0 = 16 * kb;
+        if (wv == 0) {
+            const int r = lane & 15;                       // lanes 16..63 mirror lanes 0..15 (no divergence)
+            double a[16], x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = Gs[(j0 + r) * CH_LD + j0 + c];
+            double my_invd = 1.0;
+            unsigned rejected = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double v = bcast(a[j], j);
+                const bool live = j0 + j < n;
+                const bool ok = live && v > piv_tol;
+                if (live && !ok) rejected |= 1u << j;
+                const double d = ok ? sqrt(v) : 1.0, inv_d = ok ? 1.0 / d : 0.0;
+                if (r == j) my_invd = ok ? inv_d : 1.0;
+                a[j] = (r == j) ? d : ((r > j) ? a[j] * inv_d : 0.0);          // column j of L11
+#pragma unroll
+                for (int k = j + 1; k < 16; ++k) {
+                    const double lkj = bcast(a[j], k);
+                    if (r >= k) a[k] = fma(-a[j], lkj, a[k]);
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) Gs[(j0 + r) * CH_LD + j0 + c] = a[c];
+                sh_invd[j0 + r] = my_invd;
+            }
+            if (rejected && lane == 0) sh_bad = 1;
+            // lane c: column c of L11^-1 by forward substitution, L11[i][k] = a[k] of lane i
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double sacc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) sacc = fma(-bcast(a[k], i), x[k], sacc);   // x[k] = 0 for k < c
+                const double idi = bcast(my_invd, i);
+                x[i] = (i >= r && !((rejected >> i) & 1u)) ? sacc * idi : 0.0;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh_linv[i][r] = x[i];
+            }
+        }
         __syncthreads();
-        const double v = sh_col[j];
-        const bool ok = v > piv_tol;
-        if (tid == 0 && !ok) sh_bad = 1;
-        // a rejected pivot zeroes its column (the direction is dropped, as pinv would)
-        const double d = ok ? sqrt(v) : 1.0, inv_v = ok ? 1.0 / v : 0.0, inv_d = ok ? 1.0 / d : 0.0;
-        if (tid == j) { Gs[j * CH_LD + j] = d; sh_invd[j] = ok ? inv_d : 1.0; }
-        if (tid > j && tid < n) Gs[tid * CH_LD + j] = sh_col[tid] * inv_d;
-        if (ri > j && ri < n) {
-            const double ci = sh_col[ri] * inv_v;
-            double* Gi = Gs + ri * CH_LD;
-            for (int k = j + 1 + part; k <= ri; k += 8) Gi[k] = fma(-ci, sh_col[k], Gi[k]);
+        // (b) panel: row tile rt of L21 = A21[rt] * L11^-T  (B operand [k][n] = L11^-1[n][k])
+        const int ntile = (n + 15) / 16;
+        {
+            const int rt = kb + 1 + wv;
+            if (rt < ntile) {
+                f64x4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += 4)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(Gs[(rt * 16 + lr) * CH_LD + j0 + k0 + lq],
+                                                             sh_linv[lr][k0 + lq], c, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Gs[(rt * 16 + 4 * i + lq) * CH_LD + j0 + lr] = c[i];
+            }
+        }
+        __syncthreads();
+        // (c) trailing update of the lower tiles (ti >= tj > kb): A22[ti][tj] -= L21[ti] L21[tj]^T
+        {
+            const int mt = ntile - kb - 1, cnt = mt * (mt + 1) / 2;
+            for (int t = wv; t < cnt; t += 16) {
+                int di = 0;
+                while ((di + 1) * (di + 2) / 2 <= t) ++di;
+                const int ti = kb + 1 + di, tj = kb + 1 + t - di * (di + 1) / 2;
+                f64x4 c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = Gs[(ti * 16 + 4 * i + lq) * CH_LD + tj * 16 + lr];
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += 4)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-Gs[(ti * 16 + lr) * CH_LD + j0 + k0 + lq],
+                                                             Gs[(tj * 16 + lr) * CH_LD + j0 + k0 + lq], c, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Gs[(ti * 16 + 4 * i + lq) * CH_LD + tj * 16 + lr] = c[i];
+            }
         }
         __syncthreads();
     }
@@ -384,13 +477,62 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
 
     // ---- phase 5: W_out ---------------------------------------------------------------------
     if (wide) {
-        // W_out[o][c] = sum_i A[i][c] alpha[i][o]   (a hand-unrolled 8-loads-in-flight form measured slower)
-        for (int e = tid; e < ((sp.skip & 8) ? 0 : nrhs * cols); e += 1024) {
-            const int o = e / cols, c = e % cols;
-            const double* al = Bs + o * CH_NP;
-            double a = 0.0;
-            for (int i = 0; i < n; ++i) a = fma(A[(size_t)i * cols + c], al[i], a);
-            sp.W_out[((size_t)g * nrhs + o) * cols + c] = a;
+        // W_out[o][c] = sum_i A[i][c] alpha[i][o].  Every element of A is fetched once, by 16-byte
+        // loads: thread (third, pair) sums a third of the rows for columns 2 pair, 2 pair + 1 and all
+        // nrhs outputs; the three partial sums meet in LDS (the factor is no longer needed).  HBM
+        // latency-bound: ~12 waves x 8 loads x 1 KB in flight per CU.
+        const int npair = cols / 2;
+        if ((cols & 1) == 0 && 3 * npair <= 1024 && 3 * npair * 16 <= CH_NP * CH_LD && !(sp.skip & 8)) {
+            double* part = Gs;                               // [3][nrhs<=8][cols]
+            const int third = tid / npair, pr = tid - third * npair;
+            if (third < 3) {
+                const int per = (n + 2) / 3;
+                const int i0 = third * per, i1 = (i0 + per < n) ? i0 + per : n;
+                double w0[8], w1[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) { w0[o] = 0.0; w1[o] = 0.0; }
+                const double* Ac = A + 2 * pr;
+#pragma unroll 8
+                for (int i = i0; i < i1; ++i) {
+                    const double2 a = *reinterpret_cast<const double2*>(Ac + (size_t)i * cols);
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+                        if (o < nrhs) {
+                            const double al = Bs[o * CH_NP + i];
+                            w0[o] = fma(a.x, al, w0[o]);
+                            w1[o] = fma(a.y, al, w1[o]);
+                        }
+                }
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o < nrhs) {
+                        part[(third * 8 + o) * cols + 2 * pr] = w0[o];
+                        part[(third * 8 + o) * cols + 2 * pr + 1] = w1[o];
+                    }
+            }
+            __syncthreads();
+            for (int e = tid; e < nrhs * cols; e += 1024) {
+                const int o = e / cols, c = e - o * cols;
+                sp.W_out[((size_t)g * nrhs + o) * cols + c] =
+                    (part[o * cols + c] + part[(8 + o) * cols + c]) + part[(16 + o) * cols + c];
+            }
+        } else {
+            for (int c = tid; c < ((sp.skip & 8) ? 0 : cols); c += 1024) {
+                double w[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) w[o] = 0.0;
+                const double* Ac = A + c;
+#pragma unroll 8
+                for (int i = 0; i < n; ++i) {
+                    const double a = Ac[(size_t)i * cols];
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+                        if (o < nrhs) w[o] = fma(a, Bs[o * CH_NP + i], w[o]);
+                }
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o < nrhs) sp.W_out[((size_t)g * nrhs + o) * cols + c] = w[o];
+            }
         }
     } else {
         for (int e = tid; e < nrhs * cols; e += 1024) {
