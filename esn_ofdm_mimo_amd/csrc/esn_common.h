@@ -216,8 +216,11 @@ __device__ __forceinline__ float tanh_prescaled(float z) {
 #ifdef ESN_STAMPS
 #define ESN_STAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define ESN_STAMP_SET(var) { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define ESN_STAMP(var)
+#define ESN_STAMP_SET(var)
 #endif
 
 }  // namespace esn

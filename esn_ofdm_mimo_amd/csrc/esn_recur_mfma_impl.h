@@ -735,6 +735,32 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 #ifdef ESN_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
+    // Harvest: few sequences (one pilot per trained ESN), so a launch is a handful of workgroups
+    // whose critical path is the weight stream of every step.  Same recipe as the skewed
+    // schedule: HD k-groups in flight per wave in fixed buffers, refilled by buffer loads right
+    // after their last MFMA, nothing conditional.  The k sequence is padded to a multiple of HD
+    // positions per step (positions >= nkg: out-of-range offset, zero fragments, no traffic) so
+    // the buffers keep their phase across steps and the look-ahead runs through phase E.
+    constexpr int HD = (NW * MT * NT >= 64) ? 2 : 4;      // 16 waves x 64 accumulators: 128-VGPR budget, two buffers
+    u32x4 hbuf[HD][MT];
+    const int h_npos = (nkg + HD - 1) / HD * HD;
+    const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride), 0,
+        (int)p.wset_stride, 0x00020000);
+    const int h_row0 = wave * MT * nkg;
+    auto hload = [&](u32x4 (&a)[MT], int pos) {
+        const int kg = pos >= h_npos ? pos - h_npos : pos;
+        const bool live = kg < nkg;
+        const int voff = live ? lane * 16 : 0x7ffffff0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            a[mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                h_rsrc, voff, live ? (h_row0 + mt * nkg + kg) * 1024 : 0, 0));
+    };
+    if constexpr (HARVEST) {
+#pragma unroll
+        for (int j = 0; j < HD; ++j) hload(hbuf[j], j);
+    }
     for (int s = 0; s < p.S; ++s) {
         ESN_STAMP(t0)
         const bool have_next = s + 1 < p.S;
@@ -747,7 +773,34 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-
+#ifdef ESN_STAMPS
+        unsigned long long t1 = 0, t2 = 0;
+#endif
+        if constexpr (HARVEST) {
+            u32x4 hb[NT];
+            auto hloadB = [&](int kg) {
+                kg = kg < nkg ? kg : nkg - 1;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    hb[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + kg * 32);
+            };
+            hloadB(0);
+            for (int i = 0; i < h_npos; i += HD) {
+#pragma unroll
+                for (int j = 0; j < HD; ++j) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) TR::mma32(acc[mt][nt], hbuf[j][mt], hb[nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    hload(hbuf[j], i + j + HD);
+                    hloadB(i + j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            ESN_STAMP_SET(t1)
+            ESN_STAMP_SET(t2)
+        } else {
         // software pipeline: A fragments two k-groups ahead (L2 latency), B fragments one ahead (LDS)
         u32x4 aA[MT], aB[MT], aC[MT], bA[NT], bB[NT];
         // position i of the k sequence -> k-group: the state groups are walked from a per-tile
@@ -820,9 +873,9 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             }
         }
         if (ro_now) finish_readout(s - 1 - p.transient, true);
-        ESN_STAMP(t1)
+        ESN_STAMP_SET(t1)
         if (!HARVEST) __syncthreads();            // F_s visible to every wave
-        ESN_STAMP(t2)
+        ESN_STAMP_SET(t2)
         // ================= phase G2: input + feedback k-groups =====================
         loadB(bA, nkgS);
         for (int kg = nkgS; kg < nkg; ++kg) {
@@ -833,6 +886,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             for (int nt = 0; nt < NT; ++nt) bA[nt] = bB[nt];
         }
         if (any_ro) readout_groups(nk64S, nk64);  // yU_s (feedback columns carry zero weights)
+        }   // !HARVEST
         ESN_STAMP(t3)
         __syncthreads();                          // every wave has finished reading Z_s
         ESN_STAMP(t4)
