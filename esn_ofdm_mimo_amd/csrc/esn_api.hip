@@ -218,6 +218,7 @@ int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packe
     p.U = U; p.D = D; p.noise_u = noise_u;
     p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
     p.E = E;
+    ESN_SET_STAMPS(p);
     int e = (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
                                    : launch_recur_mfma(precision, p, (hipStream_t)stream);
     return hip_fail(e, "esn_harvest_batch");

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     }
 
 #ifdef ESN_STAMPS
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
     // Harvest: few sequences (one pilot per trained ESN), so a launch is a handful of workgroups
     // whose critical path is the weight stream of every step.  Same recipe as the skewed
@@ -761,10 +761,64 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 #pragma unroll
         for (int j = 0; j < HD; ++j) hload(hbuf[j], j);
     }
+    // E row `erow`, state columns, straight from the LDS image: wave w copies frames w, w + NW, ...;
+    // (Tried: issuing these stores inside the GEMM loop -- they share vmcnt with the weight loads
+    // and doubled the loop time.)
+    auto copy_row = [&](int erow) {
+        for (int f = wave; f < BT; f += NW) {
+            const int fr = tab_fr[f];
+            if (fr < 0) continue;
+            double* er = p.E + ((size_t)fr * (p.S + 1) + erow) * ncols;
+            const char* zr = zt + (size_t)f * row_bytes;
+            if ((ncols & 1) == 0) {          // 16-byte stores, two columns per lane: the tail is store-issue bound
+                for (int c0 = 0; c0 < n_res; c0 += 512) {
+                    float v[4][2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + 128 * u + 2 * lane;
+                        v[u][0] = c < n_res ? TR::load1(zr + (size_t)c * ES) : 0.f;
+                        v[u][1] = c + 1 < n_res ? TR::load1(zr + (size_t)(c + 1) * ES) : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + 128 * u + 2 * lane;
+                        if (c + 1 < n_res) *reinterpret_cast<double2*>(er + c) = double2{(double)v[u][0], (double)v[u][1]};
+                        else if (c < n_res) er[c] = (double)v[u][0];
+                    }
+                }
+            } else {
+                for (int c = lane; c < n_res; c += 64) er[c] = (double)TR::load1(zr + (size_t)c * ES);
+            }
+        }
+    };
     for (int s = 0; s < p.S; ++s) {
         ESN_STAMP(t0)
         const bool have_next = s + 1 < p.S;
         if (in_dma && have_next) dma_inputs(s + 1);          // lands in in_raw while the GEMM runs
+        // harvest: thread t fetches input element t and teacher element t of step s+1 now, into two
+        // registers, and converts them in phase E -- the HBM latency hides under the GEMM (staging
+        // by the two column-owner waves alone cost 9k of the 26k cycles of a harvest step)
+        double pre_in = 0.0, pre_t = 0.0;
+        int pre_fr_in = -1, pre_fr_t = -1;
+        const bool pre_ok = HARVEST && BT * kin_p <= NTHREADS && BT * kfb_p <= NTHREADS;
+        if (HARVEST && pre_ok && have_next) {
+            if (tid < BT * kin_p) {
+                const int f = tid / kin_p, ci = tid - f * kin_p;
+                const int fr = tab_fr[f], row = s + 1 + p.in_row_off;
+                if (fr >= 0 && ci < n_in) {
+                    pre_fr_in = fr;
+                    if (row < p.T_in) pre_in = p.U[(size_t)fr * in_stride + (size_t)row * n_in + ci];
+                }
+            }
+            if (tid < BT * kfb_p) {
+                const int f = tid / kfb_p, co = tid - f * kfb_p;
+                const int fr = tab_fr[f];
+                if (fr >= 0 && co < n_out) {
+                    pre_fr_t = fr;
+                    pre_t = p.D[((size_t)fr * (p.S + 1) + (s + 1)) * n_out + co];
+                }
+            }
+        }
         // ================= phase G1: state k-groups (+ readout of Y_s) ===========
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -798,6 +852,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+
             ESN_STAMP_SET(t1)
             ESN_STAMP_SET(t2)
         } else {
@@ -893,7 +948,36 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 
         // ================= phase E: X_{s+1} = tanh(P) + noise =====================
         // next step's inputs first: the HBM latency hides under the activation arithmetic
-        if (have_next) {
+        if (HARVEST && pre_ok) {
+            if (have_next) {
+                if (tid < BT * kin_p) {                       // same arithmetic as load_in / stage_teacher
+                    const int f = tid / kin_p, ci = tid - f * kin_p;
+                    float v = 0.f;
+                    if (pre_fr_in >= 0) {
+                        int pg;
+                        slot_frame(p, slot0 + f, pg);
+                        const double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + ci] : 1.0;
+                        const double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + ci] : 0.0;
+                        const double sv = pre_in * sc + sh;
+                        p.E[((size_t)pre_fr_in * (p.S + 1) + (s + 1 + p.in_row_off)) * ncols + n_res + ci] = sv;
+                        v = (float)sv;
+                    }
+                    TR::store1(zt + (size_t)f * row_bytes + (size_t)(g.kin + ci) * ES, v);
+                }
+                if (tid < BT * kfb_p) {
+                    const int f = tid / kfb_p, co = tid - f * kfb_p;
+                    float v = 0.f;
+                    if (pre_fr_t >= 0) {
+                        int pg;
+                        slot_frame(p, slot0 + f, pg);
+                        const double sc = p.t_scale ? p.t_scale[(size_t)pg * n_out + co] : 1.0;
+                        const double sh = p.t_shift ? p.t_shift[(size_t)pg * n_out + co] : 0.0;
+                        v = (float)(pre_t * sc + sh);
+                    }
+                    TR::store1(zt + (size_t)f * row_bytes + (size_t)(g.kfb + co) * ES, v);
+                }
+            }
+        } else if (have_next) {
             if (in_dma) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own DMA (issued a GEMM ago)
                 commit_inputs(s + 1);
@@ -944,19 +1028,11 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         ESN_STAMP(t5)
         __syncthreads();                          // X_{s+1}, U_{s+1} (, F_{s+1}) complete
         ESN_STAMP(t6)
-        if (HARVEST) {
-            // E row s+1, state columns, straight from the LDS image: wave w copies frames w, w+NW, ...
-            for (int f = wave; f < BT; f += NW) {
-                const int fr = tab_fr[f];
-                if (fr < 0) continue;
-                double* er = p.E + ((size_t)fr * (p.S + 1) + (s + 1)) * ncols;
-                const char* zr = zt + (size_t)f * row_bytes;
-                for (int c = lane; c < n_res; c += 64) er[c] = (double)TR::load1(zr + (size_t)c * ES);
-            }
-        }
+        if (HARVEST) copy_row(s + 1);
+        ESN_STAMP(t7)
 #ifdef ESN_STAMPS
         st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2;
-        st_acc[3] += t4 - t3; st_acc[4] += t5 - t4; st_acc[5] += t6 - t5;
+        st_acc[3] += t4 - t3; st_acc[4] += t5 - t4; st_acc[5] += t6 - t5; st_acc[6] += t7 - t6;
 #endif
     }
     // final readout Y_S = yU_{S-1} + Wout_x X_S
@@ -966,7 +1042,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     }
 #ifdef ESN_STAMPS
     if (p.stamps && blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 6; ++i) p.stamps[wave * 8 + i] = st_acc[i];
+        for (int i = 0; i < 7; ++i) p.stamps[wave * 8 + i] = st_acc[i];
 #endif
 }
 

@@ -23,7 +23,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "f16"
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 params = LinkParams()
 F = params.coherence_symbols
-sweep = DetectorSweep(params, n_reservoir=512, noise=0.001, seed=1, precision=prec, fit_precision="f32")
+sweep = DetectorSweep(params, n_reservoir=512, noise=0.001, seed=1, precision=prec, fit_precision=os.environ.get("ESN_FIT", "f32"))
 lib = _lib.load()
 lib.esn_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 buf = torch.zeros(16 * 8, dtype=torch.int64, device="cuda")
@@ -31,6 +31,19 @@ lib.esn_debug_set_stamp_buffer(buf.data_ptr())
 data = sweep.src.blocks_fast(12.0, 0, 0, G, F)
 sweep.set_snr(12.0, G)
 sweep.train(data["pilot_y"], data["pilot_x"], seed=1)
+if len(sys.argv) > 3 and sys.argv[3] == "harvest":      # stamps of the last harvest launch (workgroup 0)
+    buf.zero_()
+    sweep.train(data["pilot_y"], data["pilot_x"], seed=1)
+    torch.cuda.synchronize()
+    raw = buf.cpu().numpy().reshape(16, 8)
+    Th = params.t_frame + params.delay
+    names = ["G gemm", "-", "-", "wait", "E + staging", "wait", "E-row copy"]
+    print("harvest: cycles per timestep (workgroup 0), per wave")
+    print("wave " + " ".join(f"{n:>12s}" for n in names) + "        total")
+    for w in range(8):
+        v = raw[w, :7].astype(float) / Th
+        print(f"{w:4d} " + " ".join(f"{x:12.0f}" for x in v) + f" {v.sum():12.0f}")
+    sys.exit(0)
 U = torch.view_as_real(data["data_y"]).reshape(G * F, params.t_frame, sweep.n_in)
 T = params.t_frame + params.delay
 for _ in range(2):
