@@ -1,4 +1,4 @@
-// Fused detector tail, one workgroup per (frame, tx antenna):
+// Fused detector tail, one workgroup per frame, one wave per tx antenna:
 //   x[n] = Y[frame][n][2tx] + j Y[frame][n][2tx+1]            (driver :47-58, delay offset 0)
 //   X    = FFT_N(x) / (N sqrt(Pi))                             (driver :439-441)
 //   idx  = nearest point of the unit-power square QAM grid     (driver :17-28, :95-103)
@@ -9,32 +9,49 @@
 namespace esn {
 
 
+// One workgroup per frame, one wave per tx antenna (n_t <= 16): the frame's rows are read once,
+// fully coalesced (a row is n_t complex doubles), the twiddles come from one table per workgroup
+// (same sincospi arguments as the reference order, so the spectrum is bit-identical to computing
+// them per butterfly), and each antenna's FFT stays inside its wave.
 __global__ __launch_bounds__(1024) void detect_count_kernel(DetectParams dp) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    double2* buf = reinterpret_cast<double2*>(dsm);
+    const int N = dp.n_sub, n_t = dp.n_t, tid = threadIdx.x, half = N >> 1;
+    const int nthr = blockDim.x;
+    const int na_max = nthr >> 6;                            // antennas per workgroup (all of them unless LDS is short)
+    const int n_chunks = (n_t + na_max - 1) / na_max;
+    const int ld = N + 1;                                    // row pad: stage strides are powers of two
+    double2* buf = reinterpret_cast<double2*>(dsm);          // [n_t][ld]
+    double2* tw = buf + (size_t)na_max * ld;                 // [N/2]  exp(-2 pi i k / N)
     __shared__ int red[16];
-    const int N = dp.n_sub, tid = threadIdx.x, half = N >> 1;
-    const int frame = blockIdx.x / dp.n_t, tx = blockIdx.x % dp.n_t;
+    const int frame = blockIdx.x / n_chunks;
+    const int a0 = (blockIdx.x - frame * n_chunks) * na_max;
+    const int na = (n_t - a0 < na_max) ? n_t - a0 : na_max;
     const int group = frame / dp.frames_per_group;
-    const double* y = dp.Y + (size_t)frame * N * 2 * dp.n_t + 2 * tx;
+    const double2* y = reinterpret_cast<const double2*>(dp.Y) + (size_t)frame * N * n_t;
 
-    // bit-reversed load
-    for (int i = tid; i < N; i += blockDim.x) {
-        int rv = (int)(__brev((unsigned)i) >> (32 - dp.log2n));
-        buf[rv] = make_double2(y[(size_t)i * 2 * dp.n_t], y[(size_t)i * 2 * dp.n_t + 1]);
+    for (int k = tid; k < half; k += nthr) {
+        double sn, cs;
+        sincospi(-2.0 * (double)k / (double)N, &sn, &cs);
+        tw[k] = make_double2(cs, sn);
+    }
+    for (int i = tid; i < N * na; i += nthr) {               // bit-reversed load, element i = (row, antenna)
+        const int row = i / na, ant = i - row * na;
+        const int rv = (int)(__brev((unsigned)row) >> (32 - dp.log2n));
+        buf[ant * ld + rv] = y[(size_t)row * n_t + a0 + ant];
     }
     __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    double2* b = buf + (size_t)wv * ld;                      // this wave's antenna
     for (int s = 1; s <= dp.log2n; ++s) {
-        const int hm = 1 << (s - 1);
-        if (tid < half) {
-            const int j = tid & (hm - 1);
-            const int base = ((tid >> (s - 1)) << s) + j;
-            double sn, cs;
-            sincospi(-(double)j / (double)hm, &sn, &cs);       // w = exp(-2 pi i j / 2^s)
-            double2 a = buf[base], b = buf[base + hm];
-            double tr = b.x * cs - b.y * sn, ti = b.x * sn + b.y * cs;
-            buf[base] = make_double2(a.x + tr, a.y + ti);
-            buf[base + hm] = make_double2(a.x - tr, a.y - ti);
+        const int hm = 1 << (s - 1), tstep = N >> s;
+        for (int t = lane; t < (wv < na ? half : 0); t += 64) {
+            const int j = t & (hm - 1);
+            const int base = ((t >> (s - 1)) << s) + j;
+            const double2 w = tw[j * tstep];                 // exp(-2 pi i j / 2^s)
+            const double2 a = b[base], c = b[base + hm];
+            const double tr = c.x * w.x - c.y * w.y, ti = c.x * w.y + c.y * w.x;
+            b[base] = make_double2(a.x + tr, a.y + ti);
+            b[base + hm] = make_double2(a.x - tr, a.y - ti);
         }
         __syncthreads();
     }
@@ -43,38 +60,44 @@ __global__ __launch_bounds__(1024) void detect_count_kernel(DetectParams dp) {
     const double norm = sqrt(2.0 * (double)(side * side - 1) / 3.0);
     const double scale = 1.0 / ((double)N * sqrt(dp.p_i[group]));
     int errs = 0;
-    for (int k = tid; k < N; k += blockDim.x) {
-        double2 v = buf[k];
-        double re = v.x * scale, im = v.y * scale;
-        if (dp.X_hat) {
-            double* xo = dp.X_hat + ((size_t)frame * N + k) * 2 * dp.n_t + 2 * tx;
-            xo[0] = re; xo[1] = im;
-        }
+    for (int e = tid; e < N * na; e += nthr) {               // element e = (subcarrier k, antenna), antenna fastest
+        const int k = e / na, ant = a0 + e - k * na;
+        const double2 v = buf[(ant - a0) * ld + k];
+        const double re = v.x * scale, im = v.y * scale;
+        if (dp.X_hat)
+            reinterpret_cast<double2*>(dp.X_hat)[((size_t)frame * N + k) * n_t + ant] = make_double2(re, im);
         int i = (int)rint((re * norm + (double)(side - 1)) * 0.5);
         int j = (int)rint((im * norm + (double)(side - 1)) * 0.5);
         i = min(max(i, 0), side - 1);
         j = min(max(j, 0), side - 1);
         const int idx = i * side + j;
-        const uint8_t* tb = dp.tx_bits + ((size_t)frame * N * dp.m + (size_t)k * dp.m) * dp.n_t + tx;
-        for (int b = 0; b < dp.m; ++b) errs += (((idx >> b) & 1) != (int)tb[(size_t)b * dp.n_t]);
+        const uint8_t* tb = dp.tx_bits + ((size_t)frame * N + k) * dp.m * n_t + ant;
+        for (int bb = 0; bb < dp.m; ++bb) errs += (((idx >> bb) & 1) != (int)tb[(size_t)bb * n_t]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) errs += __shfl_down(errs, off);
-    const int lane = tid & 63, wv = tid >> 6, nwv = (blockDim.x + 63) >> 6;
+    const int nwv = (nthr + 63) >> 6;
     if (lane == 0) red[wv] = errs;
     __syncthreads();
     if (tid == 0) {
         int e = 0;
         for (int w = 0; w < nwv; ++w) e += red[w];
         atomicAdd(reinterpret_cast<unsigned long long*>(dp.err + group), (unsigned long long)e);
-        atomicAdd(reinterpret_cast<unsigned long long*>(dp.bits + group), (unsigned long long)(N * dp.m));
+        atomicAdd(reinterpret_cast<unsigned long long*>(dp.bits + group), (unsigned long long)(N * dp.m * na));
     }
 }
 
 int launch_detect_count(const DetectParams& dp, hipStream_t stream) {
-    const int threads = dp.n_sub / 2 < 64 ? 64 : dp.n_sub / 2;
-    const size_t lds = sizeof(double2) * (size_t)dp.n_sub;
-    hipLaunchKernelGGL(detect_count_kernel, dim3(dp.n_frames * dp.n_t), dim3(threads), lds, stream, dp);
+    int na = dp.n_t < 16 ? dp.n_t : 16;                      // antennas (waves) per workgroup
+    auto lds_of = [&](int a) { return sizeof(double2) * ((size_t)a * (dp.n_sub + 1) + dp.n_sub / 2); };
+    while (na > 1 && lds_of(na) > 150 * 1024) --na;
+    const size_t lds = lds_of(na);
+    if (lds > 150 * 1024) return -1;
+    const int n_chunks = (dp.n_t + na - 1) / na;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(detect_count_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(detect_count_kernel, dim3(dp.n_frames * n_chunks), dim3(64 * na), lds, stream, dp);
     return (int)hipGetLastError();
 }
 
