@@ -526,15 +526,18 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             for (int j = 0; j < 4; ++j) loadA(abuf[j], j);
         };
         // E for column tiles [NT0, NT1).  fp16 + counter noise takes a packed-half tail: the four noise
-        // bytes of a quad become two pairs of halves 1024 + byte (one v_perm_b32 each, exponent byte
-        // 0x64), and   x = tanh + noise ((byte + 1/2)/256 - 1/2)   is one v_pk_fma_f16 per pair,
-        //   x = (1024 + byte) c1 + t,   t = half(1 - 2/(1 + 2^z) + c0 - 1024 c1),  c1 = noise/256
-        // instead of four conversions, four adds and four fmas in float32.
+        // bytes of a quad become two pairs of halves 1 + byte/1024 (one v_perm_b32 each, high byte
+        // 0x3C), and   x = tanh + noise ((byte + 1/2)/256 - 1/2)   is one v_pk_fma_f16 per pair,
+        //   x = (1 + byte/1024) c1 + t,   t = half(1 - 2/(1 + 2^z) + c0 - c1),  c1 = half(4 noise)
+        // instead of four conversions, four adds and four fmas in float32.  (c1 is a normal half --
+        // noise/256 itself would be subnormal -- and t is offset by the ROUNDED c1, so the rounding
+        // of c1 changes the noise width by 2^-11 relative and adds no bias.)
         constexpr bool PK_NOISE = NOISE == ESN_NOISE_COUNTER && std::is_same<TR, TraitsF16>::value;
-        const float t_bias = 1.0f + n_c0 - 1024.0f * n_c1;
         typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const h16x2 c1h = {(_Float16)n_c1, (_Float16)n_c1};
+        const _Float16 c1s = (_Float16)(1024.0f * n_c1);
+        const h16x2 c1h = {c1s, c1s};
+        const float t_bias = 1.0f + n_c0 - (float)c1s;
         auto activate = [&](int s, auto nt0_tag, auto nt1_tag, const int (&frs)[NT / 2]) {
             constexpr int NT0 = decltype(nt0_tag)::value, NT1 = decltype(nt1_tag)::value;
 #pragma unroll
@@ -561,8 +564,8 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                                 t[j] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), t_bias);
                             }
                             const uint32_t sq = noise_mix(key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U);
-                            const h16x2 w01 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, sq, 0x04010400u));
-                            const h16x2 w23 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x64646464u, sq, 0x04030402u));
+                            const h16x2 w01 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x3C3C3C3Cu, sq, 0x04010400u));
+                            const h16x2 w23 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x3C3C3C3Cu, sq, 0x04030402u));
                             const h16x2 t01 = __builtin_convertvector(f32x2{t[0], t[1]}, h16x2);
                             const h16x2 t23 = __builtin_convertvector(f32x2{t[2], t[3]}, h16x2);
                             const h16x2 x01 = __builtin_elementwise_fma(w01, c1h, t01);

@@ -164,6 +164,47 @@ def test_ragged_batch_and_groups(amd, precision):
         assert rel_err(got[b], want) < tol, (precision, b, rel_err(got[b], want))
 
 
+@pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3)])
+def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise):
+    """The fp16 N_res=512 predict kernel runs the skewed wave schedule; ESN_SKEW=0 selects the in-step
+    schedule of the same arithmetic.  Ragged groups (tiles straddle groups and padding slots), short
+    inputs (rows past T_in are zeros), per-group read-outs, initial state / feedback, both noise modes."""
+    import os
+    _, _, batched = amd
+    rs = np.random.RandomState(11)
+    n_in, n_out, n_res, t_in, t, tr, G, F = 16, 8, 512, 30, 34, 4, 5, 75
+    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=noise)
+    in_scale, in_shift = rs.rand(G, n_in) * 0.2 + 0.1, rs.randn(G, n_in) * 0.05
+    t_scale, t_shift = rs.rand(G, n_out) + 0.5, rs.randn(G, n_out) * 0.1
+    bank.set_scaling(in_scale, in_shift, t_scale, t_shift)
+    w_out = rs.randn(G, n_out, n_res + n_in) * 0.004           # weak feedback: rounding differences are not amplified
+    bank.set_readout(w_out)
+    u = rs.randn(G * F - 9, t_in, n_in)                       # last group is short
+    x0, y0 = rs.randn(G, n_res) * 0.1, rs.randn(G, n_out) * 0.1
+    kw = dict(T=t, transient=tr, precision="f16", x0=x0, y0=y0, noise_mode=noise_mode, seed=5)
+    assert os.environ.get("ESN_SKEW") is None
+    skew = bank.predict(u, F, **kw).cpu().numpy()
+    os.environ["ESN_SKEW"] = "0"
+    try:
+        plain = bank.predict(u, F, **kw).cpu().numpy()
+    finally:
+        del os.environ["ESN_SKEW"]
+    assert skew.shape == plain.shape == (G * F - 9, t - tr, n_out)
+    # same weights, same noise draws; only the summation order of the read-out and the rounding of
+    # the noise addition (packed half: one more rounding to fp16 per state) differ
+    assert rel_err(skew, plain) < (2e-3 if noise == 0.0 else 8e-3), rel_err(skew, plain)
+    if noise == 0.0:
+        for b in (0, 74, 75, 200, G * F - 10):
+            grp = b // F
+            o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[grp], input_shift=in_shift[grp],
+                             teacher_scaling=t_scale[grp], teacher_shift=t_shift[grp], random_state=1)
+            o.W, o.W_in, o.W_feedb, o.W_out = w, w_in, w_fb, w_out[grp]
+            o.laststate, o.lastoutput = x0[grp], y0[grp]
+            want = o.predict(np.vstack([u[b], np.zeros((t - t_in, n_in))]), tr, continuation=True)
+            assert rel_err(skew[b], want) < 2e-2, (b, rel_err(skew[b], want))
+
+
 @pytest.mark.parametrize("precision,tol", [("f64", 1e-11), ("f32", 1e-5)])
 def test_harvest_batch_shared_reservoir(amd, precision, tol):
     """G pilots through one shared reservoir: E[g] equals the oracle's extended states."""
