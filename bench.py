@@ -217,7 +217,7 @@ def main():
                          "frames_per_launch": frames_per_step},
             "device": _lib.device_info(),
         }
-        if not args.no_cpu_baseline and world == 1:      # reported once, at N=1 only
+        if not args.no_cpu_baseline and args.cpu_blocks > 0 and world == 1:      # reported once, at N=1 only
             out["cpu_baseline"] = cpu_baseline(params, args.n_res, args.ebno, args.cpu_blocks, F)
         print(json.dumps(out))
     if world > 1:
