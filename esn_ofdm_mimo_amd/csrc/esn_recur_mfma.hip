@@ -56,7 +56,7 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
         const char* sk = getenv("ESN_SKEW");
         const int nkgS = g->Mp * es / 32;
         const int n_uf = g->Kp * es / 32 - nkgS;
-        g->skew = (!harvest && es == 2 && NW == 8 && NT >= 2 && g->ro_parts == 1 && nkgS % 8 == 0 && n_uf <= 4 &&
+        g->skew = (!harvest && es == 2 && NW == 8 && (NT == 2 || NT == 4) && g->ro_parts == 1 && nkgS % 8 == 0 && n_uf <= 4 &&
                    (n_in == 2 || n_in == 4 || n_in == 8 || n_in == 16) &&
                    !(sk && sk[0] == '0')) ? 1 : 0;
     }

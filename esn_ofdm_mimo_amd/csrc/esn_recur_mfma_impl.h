@@ -597,14 +597,16 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         const std::integral_constant<int, 0> nt_lo;
         const std::integral_constant<int, NT / 2> nt_mid;
         const std::integral_constant<int, NT> nt_hi;
-        // Inputs: set B stages them for all column tiles (wave w: tiles 2(w - NW/2), +1).  The raw
+        // Inputs: set B stages them for all column tiles (IN_TILES consecutive tiles per wave).  The raw
         // float64 rows of step s+1 go HBM -> LDS staging area by LDS-DMA at the very end of phase
         // E of step s (slot 3s+3) and are converted into the U columns of Zt at the start of
         // P0(s+1) (slot 3s+4), the one slot in which nobody reads U.  Placement matters twice:
         // with a DMA pending the compiler puts s_waitcnt vmcnt(0) in front of the next LDS read
         // (so the DMA must not precede a GEMM loop), and staging through VGPRs instead ends in
         // scratch spills that wait for every HBM load in turn.
-        const int in_c0 = 2 * (wave - NW / 2);
+        static_assert(NOWN % (NW / 2) == 0, "skewed schedule: set B shares the column tiles evenly");
+        constexpr int IN_TILES = NOWN / (NW / 2);          // column tiles staged per wave of set B
+        const int in_c0 = IN_TILES * (wave - NW / 2);
         const int lcpf = __builtin_ctz(cpf), lkin = __builtin_ctz(kin_p);     // powers of two (mfma_geometry)
         const size_t in_frame_bytes = (size_t)in_stride * 8;
         const size_t u_base_frame = (size_t)grp0 * p.F;                       // first frame of the tile's first group
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             const int row = s + p.in_row_off;
             const bool row_ok = row < p.T_in;
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
+            for (int ti = 0; ti < IN_TILES; ++ti) {
                 const int c = in_c0 + ti;
                 for (int e0 = 0; e0 < 16 * cpf; e0 += 64) {          // wave-uniform trip count
                     const int e = e0 + lane;
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         auto commit_inputs_b = [&](int s) {
             const bool row_ok = s + p.in_row_off < p.T_in;     // (an out-of-range DMA leaves LDS untouched)
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
+            for (int ti = 0; ti < IN_TILES; ++ti) {
                 const int c = in_c0 + ti;
                 for (int e = lane; e < 16 * kin_p; e += 64) {
                     const int f = e >> lkin, ci = e & (kin_p - 1);
@@ -1076,7 +1078,7 @@ static int launch_n(const RecurParams& p, hipStream_t stream) {
 template <typename TR, int NW, int MT, int NT>
 static int launch_one(const RecurParams& p, hipStream_t stream) {
     // skewed schedule: instantiated for the 8-wave fp16 / bf16 predict tilings (mfma_geometry sets g.skew)
-    if constexpr (NW == 8 && TR::ES == 2 && NT >= 2) {
+    if constexpr (NW == 8 && TR::ES == 2 && (NT == 2 || NT == 4)) {
         if (!p.harvest && p.g.skew) return launch_n<TR, NW, MT, NT, false, true>(p, stream);
     }
     return p.harvest ? launch_n<TR, NW, MT, NT, true>(p, stream) : launch_n<TR, NW, MT, NT, false>(p, stream);

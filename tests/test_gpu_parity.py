@@ -164,15 +164,16 @@ def test_ragged_batch_and_groups(amd, precision):
         assert rel_err(got[b], want) < tol, (precision, b, rel_err(got[b], want))
 
 
+@pytest.mark.parametrize("n_res,n_in,n_out", [(256, 16, 8), (512, 16, 8), (1024, 16, 8), (512, 4, 4), (512, 2, 2)])
 @pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3)])
-def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise):
-    """The fp16 N_res=512 predict kernel runs the skewed wave schedule; ESN_SKEW=0 selects the in-step
-    schedule of the same arithmetic.  Ragged groups (tiles straddle groups and padding slots), short
+def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res, n_in, n_out):
+    """The fp16 predict kernel of 8-wave tilings (N_res 256 / 512 / 1024: 128, 128 and 64 frames per
+    tile) runs the skewed wave schedule; ESN_SKEW=0 selects the in-step schedule of the same arithmetic.  Ragged groups (tiles straddle groups and padding slots), short
     inputs (rows past T_in are zeros), per-group read-outs, initial state / feedback, both noise modes."""
     import os
     _, _, batched = amd
     rs = np.random.RandomState(11)
-    n_in, n_out, n_res, t_in, t, tr, G, F = 16, 8, 512, 30, 34, 4, 5, 75
+    t_in, t, tr, G, F = 30, 34, 4, 5, 75
     w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
     bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=noise)
     in_scale, in_shift = rs.rand(G, n_in) * 0.2 + 0.1, rs.randn(G, n_in) * 0.05
