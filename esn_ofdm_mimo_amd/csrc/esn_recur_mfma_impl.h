@@ -628,11 +628,14 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                 for (int e0 = 0; e0 < 16 * cpf; e0 += 64) {          // wave-uniform trip count
                     const int e = e0 + lane;
                     const int off = (e < 16 * cpf) ? tab_off[c * 16 + (e >> lcpf)] : -1;
-                    // padding frames and rows past T_in: offset out of range, nothing is fetched
-                    const int voff = (off >= 0 && row_ok) ? off + ((e & (cpf - 1)) << 4) : OOB;
-                    char* dst = reinterpret_cast<char*>(in_raw + (size_t)c * 16 * n_in) + (size_t)e0 * 16;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
-                                                         voff, row_ok ? row * n_in * 8 : 0, 0, 0);
+                    // padding frames, lanes past the tile and rows past T_in are masked off (EXEC): an
+                    // out-of-range lane of an LDS-DMA is NOT a safe no-op -- it landed in the staging
+                    // area of the neighbouring tile (n_in < 16, where a tile uses fewer than 64 lanes)
+                    if (off >= 0 && row_ok) {
+                        char* dst = reinterpret_cast<char*>(in_raw + (size_t)c * 16 * n_in) + (size_t)e0 * 16;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
+                                                                 off + ((e & (cpf - 1)) << 4), row * n_in * 8, 0, 0);
+                    }
                 }
             }
         };
