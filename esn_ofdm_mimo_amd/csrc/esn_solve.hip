@@ -269,8 +269,9 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     // chunk staging is register-prefetched one chunk ahead and double-buffered in LDS, so the
     // global-load latency of chunk c+1 hides under the FMAs of chunk c (one barrier per chunk)
     constexpr int EPT = CH_KC * CH_NP / 1024;          // staged elements per thread (4)
-    double stg[EPT];
-    auto fetch = [&](int k0) {
+    // two chunks in flight in registers (an HBM round trip is longer than the MFMAs of one chunk)
+    double stgA[EPT], stgB[EPT];
+    auto fetch = [&](double (&stg)[EPT], int k0) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int e = tid + 1024 * q;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
             stg[q] = (i < n && k < m) ? (wide ? A[(size_t)i * cols + k] : A[(size_t)k * cols + i]) : 0.0;
         }
     };
-    auto commit = [&](double* dst) {
+    auto commit = [&](const double (&stg)[EPT], double* dst) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int e = tid + 1024 * q;
@@ -290,13 +291,10 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
         }
     };
     double* Abuf[2] = {As, As + CH_KC * AS_LD};
-    fetch(0);
-    commit(Abuf[0]);
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = 0; k0 < ((sp.skip & 1) ? CH_KC : m); k0 += CH_KC) {
-        const bool more = k0 + CH_KC < m;
-        if (more) fetch(k0 + CH_KC);
+    const int m_run = (sp.skip & 1) ? CH_KC : m;
+    // chunk c is multiplied out of Abuf[c & 1]; `stg_next` holds chunk c+1, `stg_free` receives chunk c+2
+    auto chunk = [&](int k0, int cur, const double (&stg_next)[EPT], double (&stg_free)[EPT]) {
+        if (k0 + 2 * CH_KC < m_run) fetch(stg_free, k0 + 2 * CH_KC);
         const double* Ac = Abuf[cur];
         const int kmax = (m - k0 < CH_KC) ? m - k0 : CH_KC;
         // (rows past m and columns past n of the chunk are zero-filled by fetch)
@@ -314,9 +312,16 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
             for (int kk = 0; kk < kmax; ++kk)
                 atb = fma(Ac[kk * AS_LD + ai], Dg[(size_t)(k0 + kk) * nrhs + ao] * sc + sh, atb);
         }
-        if (more) commit(Abuf[cur ^ 1]);
+        if (k0 + CH_KC < m_run) commit(stg_next, Abuf[cur ^ 1]);
         __syncthreads();
-        cur ^= 1;
+    };
+    fetch(stgA, 0);
+    commit(stgA, Abuf[0]);
+    if (CH_KC < m_run) fetch(stgA, CH_KC);
+    __syncthreads();
+    for (int k0 = 0; k0 < m_run; k0 += 2 * CH_KC) {
+        chunk(k0, 0, stgA, stgB);
+        if (k0 + CH_KC < m_run) chunk(k0 + CH_KC, 1, stgB, stgA);
     }
     __syncthreads();
     // ---- phase 2: G and the right-hand sides into LDS ----------------------------------
