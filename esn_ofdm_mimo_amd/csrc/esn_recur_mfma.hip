@@ -60,11 +60,15 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
                    (n_in == 2 || n_in == 4 || n_in == 8 || n_in == 16) &&
                    !(sk && sk[0] == '0')) ? 1 : 0;
     }
-    // Zt image + the small frame / scale tables behind it (esn_recur_mfma_impl.h)
-    const size_t tables = 4 * (size_t)g->Bt + 8 * (size_t)(g->Bt / 16) * ((g->kfb - g->kin) + 16)
-                          + 8 * (size_t)g->Bt * n_in      // + raw input rows of the next step (LDS-DMA)
-                          + 4 * (size_t)g->Bt;            // + input offsets of the frames (skewed schedule)
-    return (size_t)g->Bt * g->Ks * es + tables <= 160 * 1024;
+    // Zt image + the small frame / scale tables behind it (esn_recur_mfma_impl.h); the skewed schedule
+    // stages the raw input rows in one 1 KB slot per DMA instruction (two per 16-frame tile)
+    auto lds_bytes = [&](int skew) {
+        const size_t staging = skew ? (size_t)(g->Bt / 16) * 2048 : 8 * (size_t)g->Bt * n_in;
+        return (size_t)g->Bt * g->Ks * es + 4 * (size_t)g->Bt + 8 * (size_t)(g->Bt / 16) * ((g->kfb - g->kin) + 16)
+               + staging + 4 * (size_t)g->Bt;     // + input offsets of the frames
+    };
+    if (g->skew && lds_bytes(1) > 160 * 1024) g->skew = 0;
+    return lds_bytes(g->skew) <= 160 * 1024;
 }
 
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream) {

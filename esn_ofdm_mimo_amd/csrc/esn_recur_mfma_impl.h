@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     // raw float64 input rows of the NEXT step, filled by LDS-DMA (no VGPRs): [NOWN][16][n_in]
     double* in_raw = reinterpret_cast<double*>(tab_un + NOWN * 16);
     // skewed schedule: byte offset of each frame's input block from the tile's base frame (-1 = padding slot)
-    int* tab_off = reinterpret_cast<int*>(in_raw + (size_t)BT * n_in);
+    int* tab_off = reinterpret_cast<int*>(in_raw + (size_t)(SKEW ? NOWN * 256 : BT * n_in));
     for (int i = tid; i < BT; i += NTHREADS) { int gtmp; tab_fr[i] = slot_frame(p, slot0 + i, gtmp); }
     for (int i = tid; i < NOWN * kin_p; i += NTHREADS) {
         const int c16 = i / kin_p, c = i % kin_p;
@@ -619,28 +619,30 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(reinterpret_cast<const char*>(p.U) + u_base_frame * in_frame_bytes), 0,
             (int)(u_left < 0x7fffffffu ? u_left : 0x7fffffffu), 0x00020000);
+        // staging layout of the skewed schedule: one 1 KB slot per DMA instruction (tile c, trip i),
+        // chunk e = 64 i + lane at byte 16 lane of slot (c, i).  Lanes that must not load (padding
+        // frames, lanes past the tile when n_in < 16, rows past T_in) get an out-of-range offset:
+        // nothing is fetched, and whatever the DMA does with such a lane stays inside its own slot
+        // (with tiles packed back to back those lanes landed in the neighbouring tile's rows).
+        char* in_slots = reinterpret_cast<char*>(in_raw);
         auto dma_inputs_b = [&](int s) {
             const int row = s + p.in_row_off;
             const bool row_ok = row < p.T_in;
 #pragma unroll
             for (int ti = 0; ti < IN_TILES; ++ti) {
                 const int c = in_c0 + ti;
-                for (int e0 = 0; e0 < 16 * cpf; e0 += 64) {          // wave-uniform trip count
-                    const int e = e0 + lane;
+                for (int i = 0; 64 * i < 16 * cpf; ++i) {            // wave-uniform trip count (<= 2)
+                    const int e = 64 * i + lane;
                     const int off = (e < 16 * cpf) ? tab_off[c * 16 + (e >> lcpf)] : -1;
-                    // padding frames, lanes past the tile and rows past T_in are masked off (EXEC): an
-                    // out-of-range lane of an LDS-DMA is NOT a safe no-op -- it landed in the staging
-                    // area of the neighbouring tile (n_in < 16, where a tile uses fewer than 64 lanes)
-                    if (off >= 0 && row_ok) {
-                        char* dst = reinterpret_cast<char*>(in_raw + (size_t)c * 16 * n_in) + (size_t)e0 * 16;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
-                                                                 off + ((e & (cpf - 1)) << 4), row * n_in * 8, 0, 0);
-                    }
+                    const int voff = (off >= 0 && row_ok) ? off + ((e & (cpf - 1)) << 4) : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        u_rsrc, (__attribute__((address_space(3))) void*)(in_slots + (size_t)(c * 2 + i) * 1024), 16,
+                        voff, row_ok ? row * n_in * 8 : 0, 0, 0);
                 }
             }
         };
         auto commit_inputs_b = [&](int s) {
-            const bool row_ok = s + p.in_row_off < p.T_in;     // (an out-of-range DMA leaves LDS untouched)
+            const bool row_ok = s + p.in_row_off < p.T_in;     // (an out-of-range DMA leaves its slot undefined)
 #pragma unroll
             for (int ti = 0; ti < IN_TILES; ++ti) {
                 const int c = in_c0 + ti;
@@ -649,7 +651,10 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     float v = 0.f;
                     if (tab_fr[c * 16 + f] >= 0 && ci < n_in) {
                         const float2 ss = tab_in[c * kin_p + ci];
-                        const double raw = row_ok ? in_raw[((size_t)c * 16 + f) * n_in + ci] : 0.0;
+                        const int ch = (f << lcpf) + (ci >> 1);                      // chunk of this element
+                        const double* src = reinterpret_cast<const double*>(
+                            in_slots + (size_t)(c * 2 + (ch >> 6)) * 1024 + (size_t)(ch & 63) * 16) + (ci & 1);
+                        const double raw = row_ok ? *src : 0.0;
                         v = fmaf((float)raw, ss.x, ss.y);
                     }
                     TR::store1(zt + (size_t)(c * 16 + f) * row_bytes + (size_t)(g.kin + ci) * ES, v);
@@ -1060,7 +1065,7 @@ template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE, bool SKE
 static int launch_k(const RecurParams& p, hipStream_t stream) {
     const int kin_p = p.g.kfb - p.g.kin, nown = p.g.Bt / 16;
     size_t lds = (size_t)p.g.Bt * p.g.Ks * TR::ES + 4 * (size_t)p.g.Bt + 8 * (size_t)nown * (kin_p + 16)
-                 + 8 * (size_t)p.g.Bt * p.n_in + 4 * (size_t)p.g.Bt;
+                 + (SKEW ? (size_t)nown * 2048 : 8 * (size_t)p.g.Bt * p.n_in) + 4 * (size_t)p.g.Bt;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE, SKEW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
