@@ -112,8 +112,11 @@ class ReservoirBank:
         return self._packed_wout[precision]
 
     # ------------------------------------------------------------------ fit
-    def harvest(self, U, D, precision="f64", noise_mode="counter", noise_u=None, seed=0):
-        """U [G,T,n_in], D [G,T,n_out] -> extended states E [G,T,n_res+n_in] (device)."""
+    def harvest(self, U, D, precision="f64", noise_mode="counter", noise_u=None, seed=0, e_dtype="f64"):
+        """U [G,T,n_in], D [G,T,n_out] -> extended states E [G,T,n_res+n_in] (device).
+
+        e_dtype "f32" (MFMA precisions only) stores E as float32 -- exact for the state columns, 6e-8
+        relative on the scaled inputs -- which halves the store tail here and the reads of `solve`."""
         torch = self.torch
         U = _as_dev(U, torch, self.device)
         D = _as_dev(D, torch, self.device)
@@ -123,12 +126,16 @@ class ReservoirBank:
         self._check_groups(g)
         nm, nz = self._noise_args(noise_mode, noise_u, (g, t - 1, self.n_reservoir))
         with torch.cuda.device(self.device):
-            E = torch.empty((g, t, self.n_reservoir + self.n_inputs), dtype=torch.float64, device=self.device)
-            check(self.lib.esn_harvest_batch(
-                PRECISIONS[precision], C.byref(self.shape), ptr(self.packed_weights(precision)),
-                ptr(self.in_scale), ptr(self.in_shift), ptr(self.t_scale), ptr(self.t_shift),
-                ptr(U), ptr(D), g, t, self.noise, nm, ptr(nz), int(seed) & (2**64 - 1), ptr(E),
-                _lib.stream_handle()), "esn_harvest_batch")
+            if e_dtype not in ("f64", "f32"):
+                raise ValueError("e_dtype must be 'f64' or 'f32'")
+            f32 = e_dtype == "f32"
+            fn = self.lib.esn_harvest_batch_f32 if f32 else self.lib.esn_harvest_batch
+            E = torch.empty((g, t, self.n_reservoir + self.n_inputs),
+                            dtype=torch.float32 if f32 else torch.float64, device=self.device)
+            check(fn(PRECISIONS[precision], C.byref(self.shape), ptr(self.packed_weights(precision)),
+                     ptr(self.in_scale), ptr(self.in_shift), ptr(self.t_scale), ptr(self.t_shift),
+                     ptr(U), ptr(D), g, t, self.noise, nm, ptr(nz), int(seed) & (2**64 - 1), ptr(E),
+                     _lib.stream_handle()), "esn_harvest_batch")
         return E
 
     def solve(self, E, D, transient, method="qr"):
@@ -139,23 +146,26 @@ class ReservoirBank:
         n_out <= 8), an order of magnitude faster; groups whose pivot test fails are re-solved
         with QR on the GPU.  "auto" = "chol" when the shape fits."""
         torch = self.torch
-        E = _as_dev(E, torch, self.device)
+        e32 = isinstance(E, torch.Tensor) and E.dtype == torch.float32       # as written by harvest(e_dtype="f32")
+        E = _as_dev(E, torch, self.device, torch.float32 if e32 else None)
         D = _as_dev(D, torch, self.device)
         g, t, cols = E.shape
         rows = t - transient
         fits = min(rows, cols) <= 128 and self.n_outputs <= 8
         if method == "auto":
             method = "chol" if fits else "qr"
+        if e32 and method != "chol":
+            E = E.double()                                                  # the QR kernel works in place on float64
         if method == "chol":
             if not fits:
                 raise ValueError("method='chol' needs min(rows, cols) <= 128 and n_outputs <= 8")
             with torch.cuda.device(self.device):
                 W_out = torch.empty((g, self.n_outputs, cols), dtype=torch.float64, device=self.device)
                 status = torch.empty(g, dtype=torch.int32, device=self.device)
-                check(self.lib.esn_readout_solve_chol_batch(
-                    ptr(E), ptr(D), g, t, int(transient), cols, self.n_outputs, ptr(self.t_scale),
-                    ptr(self.t_shift), ptr(W_out), ptr(status), _lib.stream_handle()),
-                    "esn_readout_solve_chol_batch")
+                fn = self.lib.esn_readout_solve_chol_batch_f32 if e32 else self.lib.esn_readout_solve_chol_batch
+                check(fn(ptr(E), ptr(D), g, t, int(transient), cols, self.n_outputs, ptr(self.t_scale),
+                         ptr(self.t_shift), ptr(W_out), ptr(status), _lib.stream_handle()),
+                      "esn_readout_solve_chol_batch")
             self.last_solve_status = status        # checked lazily: no host sync on the fast path
             return W_out, status
         with torch.cuda.device(self.device):
@@ -188,8 +198,8 @@ class ReservoirBank:
         return nbad
 
     def fit(self, U, D, transient=0, precision="f64", noise_mode="counter", noise_u=None, seed=0,
-            method="qr"):
-        E = self.harvest(U, D, precision, noise_mode, noise_u, seed)
+            method="qr", e_dtype="f64"):
+        E = self.harvest(U, D, precision, noise_mode, noise_u, seed, e_dtype=e_dtype)
         W_out, status = self.solve(E, D, transient, method=method)
         self.set_readout(W_out)
         self.fit_status = status

@@ -26,7 +26,7 @@ size_t solve_work_doubles(int rows, int cols, int n_out);
 int launch_readout_solve(const double* E, const double* D, int n_groups, int T, int transient,
                          int cols, int n_out, const double* t_scale, const double* t_shift,
                          double* W_out, int* status, void* workspace, hipStream_t stream);
-int launch_readout_chol(const double* E, const double* D, int n_groups, int T, int transient,
+int launch_readout_chol(const double* E, const float* E32, const double* D, int n_groups, int T, int transient,
                         int cols, int n_out, const double* t_scale, const double* t_shift,
                         double* W_out, int* status, hipStream_t stream);
 // esn_gen.hip
@@ -91,7 +91,7 @@ extern "C" {
 
 const char* esn_last_error(void) { return g_err; }
 
-int esn_abi_version(void) { return 3; }
+int esn_abi_version(void) { return 4; }
 
 int esn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -196,14 +196,15 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     return hip_fail(e, "esn_predict_batch");
 }
 
-int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
+static int harvest_common(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
                       const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
                       const double* D, int n_groups, int T, double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, double* E, void* stream) {
+                      uint64_t seed, double* E, float* E32, void* stream) {
     RecurParams p;
     int rc = fill_common(p, precision, shape, "esn_harvest_batch", true);
     if (rc) return rc;
-    if (!packed_w || !U || !D || !E) return fail(-1, "esn_harvest_batch: null pointer");
+    if (!packed_w || !U || !D || (!E && !E32)) return fail(-1, "esn_harvest_batch: null pointer");
+    if (E32 && precision == ESN_F64) return fail(-2, "esn_harvest_batch_f32: float32 states are an MFMA-kernel option (precision f32/f16/bf16)");
     if (n_groups <= 0 || T < 2) return fail(-1, "esn_harvest_batch: invalid sizes (n_groups=%d T=%d)", n_groups, T);
     if (noise_mode == ESN_NOISE_TENSOR && !noise_u) return fail(-1, "esn_harvest_batch: noise tensor missing");
     if (noise_mode < ESN_NOISE_NONE || noise_mode > ESN_NOISE_COUNTER) return fail(-1, "esn_harvest_batch: bad noise mode");
@@ -217,11 +218,29 @@ int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packe
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
     p.U = U; p.D = D; p.noise_u = noise_u;
     p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
-    p.E = E;
+    p.E = E; p.E32 = E32;
     ESN_SET_STAMPS(p);
     int e = (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
                                    : launch_recur_mfma(precision, p, (hipStream_t)stream);
     return hip_fail(e, "esn_harvest_batch");
+}
+
+int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
+                      const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
+                      const double* D, int n_groups, int T, double noise, int noise_mode, const double* noise_u,
+                      uint64_t seed, double* E, void* stream) {
+    if (!E) return fail(-1, "esn_harvest_batch: null pointer");
+    return harvest_common(precision, shape, packed_w, in_scale, in_shift, t_scale, t_shift, U, D, n_groups, T, noise,
+                          noise_mode, noise_u, seed, E, nullptr, stream);
+}
+
+int esn_harvest_batch_f32(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
+                          const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
+                          const double* D, int n_groups, int T, double noise, int noise_mode,
+                          const double* noise_u, uint64_t seed, float* E, void* stream) {
+    if (!E) return fail(-1, "esn_harvest_batch_f32: null pointer");
+    return harvest_common(precision, shape, packed_w, in_scale, in_shift, t_scale, t_shift, U, D, n_groups, T, noise,
+                          noise_mode, noise_u, seed, nullptr, E, stream);
 }
 
 size_t esn_readout_solve_workspace_bytes(int n_groups, int rows, int cols, int n_out) {
@@ -246,9 +265,20 @@ int esn_readout_solve_chol_batch(const double* E, const double* D, int n_groups,
     if (!E || !D || !W_out || !status) return fail(-1, "esn_readout_solve_chol_batch: null pointer");
     if (n_groups <= 0 || T <= 0 || transient < 0 || transient >= T || cols <= 0 || n_out <= 0)
         return fail(-1, "esn_readout_solve_chol_batch: invalid sizes");
-    return hip_fail(launch_readout_chol(E, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
+    return hip_fail(launch_readout_chol(E, nullptr, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
                                         status, (hipStream_t)stream),
                     "esn_readout_solve_chol_batch");
+}
+
+int esn_readout_solve_chol_batch_f32(const float* E, const double* D, int n_groups, int T, int transient, int cols,
+                                     int n_out, const double* t_scale, const double* t_shift, double* W_out,
+                                     int* status, void* stream) {
+    if (!E || !D || !W_out || !status) return fail(-1, "esn_readout_solve_chol_batch_f32: null pointer");
+    if (n_groups <= 0 || T <= 0 || transient < 0 || transient >= T || cols <= 0 || n_out <= 0)
+        return fail(-1, "esn_readout_solve_chol_batch_f32: invalid sizes");
+    return hip_fail(launch_readout_chol(nullptr, E, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
+                                        status, (hipStream_t)stream),
+                    "esn_readout_solve_chol_batch_f32");
 }
 
 int esn_detect_count(const double* Y, int n_frames, int frames_per_group, int n_sub, int n_t, int bits_per_sym,

@@ -51,6 +51,7 @@ struct RecurParams {
     const double* noise_u;
     double noise; int noise_mode; uint64_t seed;
     double* Y; double* E;
+    float* E32;            // harvest: when set, the extended states are stored as float32 here (E unused)
     unsigned long long* stamps;   // diagnostic build (-DESN_STAMPS) only: [block0 wave][8] cycle sums
 };
 

@@ -135,6 +135,11 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     const int n_ot = (n_out + 15) / 16;      // == 1 (mfma_geometry rejects n_out > 16)
     const int out_rows = p.S - p.transient;
     const int ncols = n_res + n_in;
+    // harvest output: float64 (the reference's dtype) or float32 (exact for the state columns of the
+    // MFMA kernels, 6e-8 relative on the input columns; half the store tail and half the solve's reads)
+    auto store_E = [&](size_t idx, double v) {
+        if (p.E32) p.E32[idx] = (float)v; else p.E[idx] = v;
+    };
 
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
     const int slot0 = tile * BT;
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                 double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + ci] : 1.0;
                 double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + ci] : 0.0;
                 double sv = raw * sc + sh;
-                p.E[((size_t)fr * (p.S + 1) + row) * ncols + n_res + ci] = sv;
+                store_E(((size_t)fr * (p.S + 1) + row) * ncols + n_res + ci, sv);
                 v = (float)sv;
             } else {
                 v = fmaf((float)raw, ss.x, ss.y);
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             int pg;
             const int fr = slot_frame(p, slot0 + f, pg);
             if (fr < 0) continue;
-            double* er = p.E + ((size_t)fr * (p.S + 1)) * ncols;
+            const size_t er0 = ((size_t)fr * (p.S + 1)) * ncols;
             for (int c = lane; c < ncols; c += 64) {
                 double v = 0.0;
                 if (c >= n_res) {
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + ci] : 0.0;
                     v = raw * sc + sh;
                 }
-                er[c] = v;
+                store_E(er0 + c, v);
             }
         }
     }
@@ -781,9 +786,19 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         for (int f = wave; f < BT; f += NW) {
             const int fr = tab_fr[f];
             if (fr < 0) continue;
-            double* er = p.E + ((size_t)fr * (p.S + 1) + erow) * ncols;
+            const size_t e0 = ((size_t)fr * (p.S + 1) + erow) * ncols;
             const char* zr = zt + (size_t)f * row_bytes;
-            if ((ncols & 1) == 0) {          // 16-byte stores, two columns per lane: the tail is store-issue bound
+            if (p.E32 && (ncols & 3) == 0) {        // float32: 16-byte stores of four columns per lane
+                for (int c = 4 * lane; c < n_res; c += 256) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = c + u < n_res ? TR::load1(zr + (size_t)(c + u) * ES) : 0.f;
+                    if (c + 3 < n_res) *reinterpret_cast<f32x4*>(p.E32 + e0 + c) = f32x4{v[0], v[1], v[2], v[3]};
+                    else
+                        for (int u = 0; u < 4; ++u) if (c + u < n_res) p.E32[e0 + c + u] = v[u];
+                }
+            } else if (!p.E32 && (ncols & 1) == 0) {   // float64: 16-byte stores, two columns per lane
+                double* er = p.E + e0;
                 for (int c0 = 0; c0 < n_res; c0 += 512) {
                     float v[4][2];
 #pragma unroll
@@ -800,7 +815,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     }
                 }
             } else {
-                for (int c = lane; c < n_res; c += 64) er[c] = (double)TR::load1(zr + (size_t)c * ES);
+                for (int c = lane; c < n_res; c += 64) store_E(e0 + c, (double)TR::load1(zr + (size_t)c * ES));
             }
         }
     };
@@ -972,7 +987,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                         const double sc = p.in_scale ? p.in_scale[(size_t)pg * n_in + ci] : 1.0;
                         const double sh = p.in_shift ? p.in_shift[(size_t)pg * n_in + ci] : 0.0;
                         const double sv = pre_in * sc + sh;
-                        p.E[((size_t)pre_fr_in * (p.S + 1) + (s + 1 + p.in_row_off)) * ncols + n_res + ci] = sv;
+                        store_E(((size_t)pre_fr_in * (p.S + 1) + (s + 1 + p.in_row_off)) * ncols + n_res + ci, sv);
                         v = (float)sv;
                     }
                     TR::store1(zt + (size_t)f * row_bytes + (size_t)(g.kin + ci) * ES, v);

@@ -14,6 +14,7 @@ namespace esn {
 
 struct SolveParams {
     const double* E; const double* D;
+    const float* E32;       // Cholesky path: extended states as float32 (E unused) -- esn_harvest_batch_f32
     int n_groups, T, transient, cols, n_out;
     const double* t_scale; const double* t_shift;
     double* W_out; int* status;
@@ -192,7 +193,7 @@ int launch_readout_solve(const double* E, const double* D, int n_groups, int T, 
                          double* W_out, int* status, void* workspace, hipStream_t stream) {
     SolveParams sp;
     const int rows = T - transient;
-    sp.E = E; sp.D = D; sp.n_groups = n_groups; sp.T = T; sp.transient = transient;
+    sp.E = E; sp.E32 = nullptr; sp.D = D; sp.n_groups = n_groups; sp.T = T; sp.transient = transient;
     sp.cols = cols; sp.n_out = n_out; sp.t_scale = t_scale; sp.t_shift = t_shift;
     sp.W_out = W_out; sp.status = status;
     sp.work = reinterpret_cast<double*>(workspace);
@@ -233,7 +234,9 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     const bool wide = rows < cols;
     const int n = wide ? rows : cols;      // Gram dimension (<= CH_NP)
     const int m = wide ? cols : rows;      // contraction length
-    const double* A = sp.E + ((size_t)g * sp.T + sp.transient) * cols;   // [rows][cols]
+    const size_t a_off = ((size_t)g * sp.T + sp.transient) * cols;
+    const double* A = sp.E ? sp.E + a_off : nullptr;                     // [rows][cols]
+    const float* A32 = sp.E32 ? sp.E32 + a_off : nullptr;                //   ... or as float32
     const double* Dg = sp.D + ((size_t)g * sp.T + sp.transient) * nrhs;
     constexpr int AS_LD = CH_NP + 4;
 
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
             int kk, i;
             if (wide) { i = e / CH_KC; kk = e % CH_KC; } else { kk = e / CH_NP; i = e % CH_NP; }
             const int k = k0 + kk;
-            stg[q] = (i < n && k < m) ? (wide ? A[(size_t)i * cols + k] : A[(size_t)k * cols + i]) : 0.0;
+            const size_t ai_ = wide ? (size_t)i * cols + k : (size_t)k * cols + i;
+            stg[q] = (i < n && k < m) ? (A32 ? (double)A32[ai_] : A[ai_]) : 0.0;
         }
     };
     auto commit = [&](const double (&stg)[EPT], double* dst) {
@@ -496,10 +500,16 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
                 double w0[8], w1[8];
 #pragma unroll
                 for (int o = 0; o < 8; ++o) { w0[o] = 0.0; w1[o] = 0.0; }
-                const double* Ac = A + 2 * pr;
+                const size_t ac = 2 * (size_t)pr;
 #pragma unroll 8
                 for (int i = i0; i < i1; ++i) {
-                    const double2 a = *reinterpret_cast<const double2*>(Ac + (size_t)i * cols);
+                    double2 a;
+                    if (A32) {
+                        const float2 af = *reinterpret_cast<const float2*>(A32 + ac + (size_t)i * cols);
+                        a = double2{(double)af.x, (double)af.y};
+                    } else {
+                        a = *reinterpret_cast<const double2*>(A + ac + (size_t)i * cols);
+                    }
 #pragma unroll
                     for (int o = 0; o < 8; ++o)
                         if (o < nrhs) {
@@ -526,10 +536,9 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
                 double w[8];
 #pragma unroll
                 for (int o = 0; o < 8; ++o) w[o] = 0.0;
-                const double* Ac = A + c;
 #pragma unroll 8
                 for (int i = 0; i < n; ++i) {
-                    const double a = Ac[(size_t)i * cols];
+                    const double a = A32 ? (double)A32[(size_t)i * cols + c] : A[(size_t)i * cols + c];
 #pragma unroll
                     for (int o = 0; o < 8; ++o)
                         if (o < nrhs) w[o] = fma(a, Bs[o * CH_NP + i], w[o]);
@@ -548,10 +557,11 @@ __global__ __launch_bounds__(1024) void readout_chol_kernel(SolveParams sp) {
     if (tid == 0) sp.status[g] = sh_bad;
 }
 
-int launch_readout_chol(const double* E, const double* D, int n_groups, int T, int transient,
+int launch_readout_chol(const double* E, const float* E32, const double* D, int n_groups, int T, int transient,
                         int cols, int n_out, const double* t_scale, const double* t_shift,
                         double* W_out, int* status, hipStream_t stream) {
     SolveParams sp;
+    sp.E32 = E32;
     const int rows = T - transient;
     const int n = rows < cols ? rows : cols;
     if (n > CH_NP || n_out > 8) return -1;     // tall case stages A^T B with nrhs*128 <= 1024 threads

@@ -257,8 +257,14 @@ class DetectorSweep:
         U[:, :t] = _view_real(pilot_y)
         D[:, d:d + t] = _view_real(pilot_x)
         self._fit_io = (U, D, d + p.cp)
+        # float32 extended states on the all-GPU fast path (fp16/bf16 harvest + Cholesky): the state
+        # columns are exactly representable, the fit is unchanged to ~1e-7
+        rows, cols = t + d - (d + p.cp), self.bank.n_reservoir + self.n_in
+        chol = self.solve_method == "chol" or (self.solve_method == "auto" and min(rows, cols) <= 128
+                                               and self.n_out <= 8)
+        e_dtype = "f32" if (chol and self.fit_precision in ("f16", "bf16")) else "f64"
         return self.bank.fit(U, D, transient=d + p.cp, precision=self.fit_precision, noise_mode="counter",
-                             seed=seed, method=self.solve_method)
+                             seed=seed, method=self.solve_method, e_dtype=e_dtype)
 
     def repair_fit(self, E):
         """Host-synchronising check of the last fit: groups the Cholesky path flagged are re-solved

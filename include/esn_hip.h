@@ -140,6 +140,18 @@ int esn_harvest_batch(int precision, const esn_shape_t* shape,
                       double noise, int noise_mode, const double* noise_u,
                       uint64_t seed, double* E, void* stream);
 
+/* Same harvest, extended states stored as float32 (MFMA precisions only: their state columns are
+ * exactly representable, the scaled-input columns round at 6e-8 relative).  Halves the harvest's
+ * store tail and the two passes esn_readout_solve_chol_batch_f32 makes over E.  No counterpart in
+ * the reference (its states are float64, :176); an internal fast path of the batched fit. */
+int esn_harvest_batch_f32(int precision, const esn_shape_t* shape,
+                          const void* packed_w,
+                          const double* in_scale, const double* in_shift,
+                          const double* t_scale, const double* t_shift,
+                          const double* U, const double* D, int n_groups, int T,
+                          double noise, int noise_mode, const double* noise_u,
+                          uint64_t seed, float* E, void* stream);
+
 /* W_out[g] = (pinv(E[g][transient:]) @ (D[g][transient:]*t_scale + t_shift)).T  (:191-192)
  *
  * float64 Householder QR: of E^T when rows < cols (minimum-norm solution, what
@@ -163,6 +175,11 @@ int esn_readout_solve_chol_batch(const double* E, const double* D, int n_groups,
                                  int transient, int cols, int n_out,
                                  const double* t_scale, const double* t_shift,
                                  double* W_out, int* status, void* stream);
+/* ... with E as written by esn_harvest_batch_f32 (arithmetic still float64). */
+int esn_readout_solve_chol_batch_f32(const float* E, const double* D, int n_groups, int T,
+                                     int transient, int cols, int n_out,
+                                     const double* t_scale, const double* t_shift,
+                                     double* W_out, int* status, void* stream);
 
 /* Fused detector tail: Y [B][N][2 N_t] time-domain ESN outputs
  * -> (1/N) FFT_N / sqrt(Pi[group]) -> nearest unit-power square-QAM point ->

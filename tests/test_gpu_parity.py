@@ -226,6 +226,37 @@ def test_harvest_batch_shared_reservoir(amd, precision, tol):
         assert rel_err(E[g], o._ext_states) < tol
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_float32_extended_states_fast_path(amd, precision):
+    """esn_harvest_batch_f32 / esn_readout_solve_chol_batch_f32: the same harvest stored as float32 and
+    the same float64 Cholesky arithmetic on it.  State columns must be bit-identical to the float64
+    harvest (MFMA states are float32/fp16 values), input columns equal to float32 rounding, and the
+    read-out equal to the float64-E read-out far below the fit's own accuracy."""
+    import torch
+    _, _, batched = amd
+    rs = np.random.RandomState(21)
+    n_in, n_out, n_res, t, tr, G = 16, 8, 512, 138, 10, 37
+    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=1e-3)
+    bank.set_scaling(rs.rand(G, n_in) * 0.2 + 0.1, rs.randn(G, n_in) * 0.05, rs.rand(G, n_out) + 0.5,
+                     rs.randn(G, n_out) * 0.1)
+    u, d = rs.randn(G, t, n_in), rs.randn(G, t, n_out) * 0.3
+    e64 = bank.harvest(u, d, precision=precision, noise_mode="counter", seed=9)
+    e32 = bank.harvest(u, d, precision=precision, noise_mode="counter", seed=9, e_dtype="f32")
+    assert e32.dtype == torch.float32 and e32.shape == e64.shape
+    assert torch.equal(e32[..., :n_res].double(), e64[..., :n_res])                  # states: exact
+    assert torch.equal(e32[..., n_res:], e64[..., n_res:].float())                   # inputs: one rounding
+    w64, st64 = bank.solve(e64, d, tr, method="chol")
+    w32, st32 = bank.solve(e32, d, tr, method="chol")
+    assert int(st64.sum()) == 0 and int(st32.sum()) == 0
+    assert rel_err(w32.cpu().numpy(), w64.cpu().numpy()) < 1e-6
+    # QR on float32 states goes through a float64 copy
+    wq, _ = bank.solve(e32, d, tr, method="qr")
+    assert rel_err(wq.cpu().numpy(), w64.cpu().numpy()) < 1e-5
+    with pytest.raises(Exception):
+        bank.harvest(u[:2], d[:2], precision="f64", e_dtype="f32")
+
+
 def test_per_group_reservoirs(amd):
     """Reference-faithful mode: one (W, W_in, W_fb) per group, fit + predict against the oracle."""
     _, _, batched = amd
