@@ -66,6 +66,10 @@ struct TraitsF32 {
     }
     static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<float*>(dst) = v; }
     static __device__ __forceinline__ float load1(const char* src) { return *reinterpret_cast<const float*>(src); }
+    static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 16-byte aligned
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
     static __device__ __forceinline__ float act(float x) { return tanh_f32(x); }
 };
 
@@ -87,6 +91,10 @@ struct TraitsF16 {
     }
     static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<_Float16*>(dst) = (_Float16)v; }
     static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const _Float16*>(src); }
+    static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 8-byte aligned
+        const h16x4 t = *reinterpret_cast<const h16x4*>(src);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
     static __device__ __forceinline__ float act(float z) { return tanh_prescaled(z); }   // weights carry 2 log2 e
 };
 
@@ -108,6 +116,10 @@ struct TraitsBF16 {
     }
     static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<__bf16*>(dst) = (__bf16)v; }
     static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const __bf16*>(src); }
+    static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 8-byte aligned
+        const b16x4 t = *reinterpret_cast<const b16x4*>(src);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
     static __device__ __forceinline__ float act(float z) { return tanh_prescaled(z); }   // weights carry 2 log2 e
 };
 
@@ -759,7 +771,8 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     // after their last MFMA, nothing conditional.  The k sequence is padded to a multiple of HD
     // positions per step (positions >= nkg: out-of-range offset, zero fragments, no traffic) so
     // the buffers keep their phase across steps and the look-ahead runs through phase E.
-    constexpr int HD = (NW * MT * NT >= 64) ? 2 : 4;      // 16 waves x 64 accumulators: 128-VGPR budget, two buffers
+    // buffers: 2 at 16 waves x 64 accumulators (128-VGPR budget), else 4 (8 measured no faster)
+    constexpr int HD = (NW * MT * NT >= 64) ? 2 : 4;
     u32x4 hbuf[HD][MT];
     const int h_npos = (nkg + HD - 1) / HD * HD;
     const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -789,13 +802,21 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             const size_t e0 = ((size_t)fr * (p.S + 1) + erow) * ncols;
             const char* zr = zt + (size_t)f * row_bytes;
             if (p.E32 && (ncols & 3) == 0) {        // float32: 16-byte stores of four columns per lane
-                for (int c = 4 * lane; c < n_res; c += 256) {
-                    float v[4];
+                // (the LDS row holds Kp >= n_res elements: reading 4 columns at c < n_res stays inside it)
+                for (int c0 = 0; c0 < n_res; c0 += 512) {
+                    float v[2][4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = c + u < n_res ? TR::load1(zr + (size_t)(c + u) * ES) : 0.f;
-                    if (c + 3 < n_res) *reinterpret_cast<f32x4*>(p.E32 + e0 + c) = f32x4{v[0], v[1], v[2], v[3]};
-                    else
-                        for (int u = 0; u < 4; ++u) if (c + u < n_res) p.E32[e0 + c + u] = v[u];
+                    for (int u = 0; u < 2; ++u) {
+                        const int c = c0 + 256 * u + 4 * lane;
+                        if (c < n_res) TR::load4(zr + (size_t)c * ES, v[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int c = c0 + 256 * u + 4 * lane;
+                        if (c + 3 < n_res) *reinterpret_cast<f32x4*>(p.E32 + e0 + c) = f32x4{v[u][0], v[u][1], v[u][2], v[u][3]};
+                        else
+                            for (int q = 0; q < 4; ++q) if (c + q < n_res) p.E32[e0 + c + q] = v[u][q];
+                    }
                 }
             } else if (!p.E32 && (ncols & 1) == 0) {   // float64: 16-byte stores, two columns per lane
                 double* er = p.E + e0;
@@ -859,28 +880,31 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         unsigned long long t1 = 0, t2 = 0;
 #endif
         if constexpr (HARVEST) {
-            u32x4 hb[NT];
-            auto hloadB = [&](int kg) {
+            // B fragments double-buffered: with two MFMAs per k-group the LDS latency of a
+            // single-buffered B operand was the critical path (285 cycles per k-group)
+            constexpr int HB = NW < 16 ? 2 : 1;              // (one buffer at 16 waves: 128-VGPR budget)
+            u32x4 hb[HB][NT];
+            auto hloadB = [&](u32x4 (&b)[NT], int kg) {
                 kg = kg < nkg ? kg : nkg - 1;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    hb[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + kg * 32);
+                    b[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + kg * 32);
             };
-            hloadB(0);
+            hloadB(hb[0], 0);
             for (int i = 0; i < h_npos; i += HD) {
 #pragma unroll
                 for (int j = 0; j < HD; ++j) {
+                    if constexpr (HB == 2) hloadB(hb[(j + 1) & 1], i + j + 1);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) TR::mma32(acc[mt][nt], hbuf[j][mt], hb[nt]);
+                        for (int mt = 0; mt < MT; ++mt) TR::mma32(acc[mt][nt], hbuf[j][mt], hb[j & (HB - 1)][nt]);
                     __builtin_amdgcn_sched_barrier(0);
                     hload(hbuf[j], i + j + HD);
-                    hloadB(i + j + 1);
+                    if constexpr (HB == 1) hloadB(hb[0], i + j + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-
             ESN_STAMP_SET(t1)
             ESN_STAMP_SET(t2)
         } else {
