@@ -626,7 +626,11 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         const int in_c0 = IN_TILES * (wave - NW / 2);
         const int lcpf = __builtin_ctz(cpf), lkin = __builtin_ctz(kin_p);     // powers of two (mfma_geometry)
         const size_t in_frame_bytes = (size_t)in_stride * 8;
-        const size_t u_base_frame = (size_t)grp0 * p.F;                       // first frame of the tile's first group
+        // first frame of the tile (frames grow with the slot index): offsets stay below Bt frames' worth
+        // of bytes however many frames a group has
+        const int j0 = slot0 - grp0 * p.Fpad;
+        size_t u_base_frame = j0 < p.F ? (size_t)grp0 * p.F + j0 : ((size_t)grp0 + 1) * p.F;
+        if (u_base_frame >= (size_t)p.n_frames) u_base_frame = (size_t)p.n_frames - 1;   // tile of padding only
         for (int i = tid; i < BT; i += NTHREADS) {
             const int fr = tab_fr[i];
             tab_off[i] = fr >= 0 ? (int)(((size_t)fr - u_base_frame) * in_frame_bytes) : -1;

@@ -164,16 +164,17 @@ def test_ragged_batch_and_groups(amd, precision):
         assert rel_err(got[b], want) < tol, (precision, b, rel_err(got[b], want))
 
 
-@pytest.mark.parametrize("n_res,n_in,n_out", [(256, 16, 8), (512, 16, 8), (1024, 16, 8), (512, 4, 4), (512, 2, 2)])
+@pytest.mark.parametrize("n_res,n_in,n_out,G,F", [(256, 16, 8, 5, 75), (512, 16, 8, 5, 75), (1024, 16, 8, 5, 75),
+                                                  (512, 4, 4, 5, 75), (512, 2, 2, 5, 75), (512, 16, 8, 2, 301)])
 @pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3)])
-def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res, n_in, n_out):
+def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res, n_in, n_out, G, F):
     """The fp16 predict kernel of 8-wave tilings (N_res 256 / 512 / 1024: 128, 128 and 64 frames per
     tile) runs the skewed wave schedule; ESN_SKEW=0 selects the in-step schedule of the same arithmetic.  Ragged groups (tiles straddle groups and padding slots), short
     inputs (rows past T_in are zeros), per-group read-outs, initial state / feedback, both noise modes."""
     import os
     _, _, batched = amd
     rs = np.random.RandomState(11)
-    t_in, t, tr, G, F = 30, 34, 4, 5, 75
+    t_in, t, tr = 30, 34, 4
     w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
     bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=noise)
     in_scale, in_shift = rs.rand(G, n_in) * 0.2 + 0.1, rs.randn(G, n_in) * 0.05
@@ -196,7 +197,7 @@ def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res,
     # the noise addition (packed half: one more rounding to fp16 per state) differ
     assert rel_err(skew, plain) < (2e-3 if noise == 0.0 else 8e-3), rel_err(skew, plain)
     if noise == 0.0:
-        for b in (0, 74, 75, 200, G * F - 10):
+        for b in (0, F - 1, F, 2 * F - 50, G * F - 10):
             grp = b // F
             o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[grp], input_shift=in_shift[grp],
                              teacher_scaling=t_scale[grp], teacher_shift=t_shift[grp], random_state=1)
