@@ -59,6 +59,7 @@ struct DetectParams {
     const double* Y; int n_frames, frames_per_group, n_sub, log2n, n_t, m;
     const double* p_i; const uint8_t* tx_bits;
     long long* err; long long* bits; double* X_hat;
+    int na_wg;             // antennas per workgroup (set by the launcher: all of them unless LDS is short)
 };
 
 // frame generator (esn_gen.hip)

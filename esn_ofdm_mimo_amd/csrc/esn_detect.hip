@@ -9,15 +9,16 @@
 namespace esn {
 
 
-// One workgroup per frame, one wave per tx antenna (n_t <= 16): the frame's rows are read once,
+// One workgroup per frame, 32 threads per tx antenna (n_t <= 16): the frame's rows are read once,
 // fully coalesced (a row is n_t complex doubles), the twiddles come from one table per workgroup
-// (same sincospi arguments as the reference order, so the spectrum is bit-identical to computing
-// them per butterfly), and each antenna's FFT stays inside its wave.
+// (same sincospi arguments as the reference order).  The radix-2 stages are taken two at a time
+// on four points in registers -- the same butterflies in the same order, so the spectrum is
+// bit-identical to the plain radix-2 loop, with half the LDS round trips and barriers.
 __global__ __launch_bounds__(1024) void detect_count_kernel(DetectParams dp) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int N = dp.n_sub, n_t = dp.n_t, tid = threadIdx.x, half = N >> 1;
     const int nthr = blockDim.x;
-    const int na_max = nthr >> 6;                            // antennas per workgroup (all of them unless LDS is short)
+    const int na_max = dp.na_wg;                             // antennas per workgroup
     const int n_chunks = (n_t + na_max - 1) / na_max;
     const int ld = N + 1;                                    // row pad: stage strides are powers of two
     double2* buf = reinterpret_cast<double2*>(dsm);          // [n_t][ld]
@@ -41,17 +42,40 @@ __global__ __launch_bounds__(1024) void detect_count_kernel(DetectParams dp) {
     }
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
-    double2* b = buf + (size_t)wv * ld;                      // this wave's antenna
-    for (int s = 1; s <= dp.log2n; ++s) {
+    const int sub = tid & 31, av = tid >> 5;                 // 32 threads per antenna
+    double2* b = buf + (size_t)av * ld;
+    const int quarter = N >> 2;
+    auto bfly = [](double2& a, double2& c, const double2 w) {
+        const double tr = c.x * w.x - c.y * w.y, ti = c.x * w.y + c.y * w.x;
+        const double2 a0 = a;
+        a = make_double2(a0.x + tr, a0.y + ti);
+        c = make_double2(a0.x - tr, a0.y - ti);
+    };
+    int s = 1;
+    for (; s + 1 <= dp.log2n; s += 2) {                      // stages s and s+1 on {base, +hm, +2hm, +3hm}
+        const int hm = 1 << (s - 1);
+        for (int t = sub; t < (av < na ? quarter : 0); t += 32) {
+            const int j = t & (hm - 1);
+            const int base = ((t >> (s - 1)) << (s + 1)) + j;
+            double2 p0 = b[base], p1 = b[base + hm], p2 = b[base + 2 * hm], p3 = b[base + 3 * hm];
+            const double2 w1 = tw[j * (N >> s)];             // exp(-2 pi i j / 2^s)
+            bfly(p0, p1, w1);
+            bfly(p2, p3, w1);
+            const int ts2 = N >> (s + 1);
+            bfly(p0, p2, tw[j * ts2]);                       // exp(-2 pi i j / 2^(s+1))
+            bfly(p1, p3, tw[(j + hm) * ts2]);
+            b[base] = p0; b[base + hm] = p1; b[base + 2 * hm] = p2; b[base + 3 * hm] = p3;
+        }
+        __syncthreads();
+    }
+    if (s <= dp.log2n) {                                     // odd number of stages: the last one alone
         const int hm = 1 << (s - 1), tstep = N >> s;
-        for (int t = lane; t < (wv < na ? half : 0); t += 64) {
+        for (int t = sub; t < (av < na ? half : 0); t += 32) {
             const int j = t & (hm - 1);
             const int base = ((t >> (s - 1)) << s) + j;
-            const double2 w = tw[j * tstep];                 // exp(-2 pi i j / 2^s)
-            const double2 a = b[base], c = b[base + hm];
-            const double tr = c.x * w.x - c.y * w.y, ti = c.x * w.y + c.y * w.x;
-            b[base] = make_double2(a.x + tr, a.y + ti);
-            b[base + hm] = make_double2(a.x - tr, a.y - ti);
+            double2 a = b[base], c = b[base + hm];
+            bfly(a, c, tw[j * tstep]);
+            b[base] = a; b[base + hm] = c;
         }
         __syncthreads();
     }
@@ -87,17 +111,19 @@ __global__ __launch_bounds__(1024) void detect_count_kernel(DetectParams dp) {
     }
 }
 
-int launch_detect_count(const DetectParams& dp, hipStream_t stream) {
-    int na = dp.n_t < 16 ? dp.n_t : 16;                      // antennas (waves) per workgroup
+int launch_detect_count(const DetectParams& dp_in, hipStream_t stream) {
+    DetectParams dp = dp_in;
+    int na = dp.n_t < 16 ? dp.n_t : 16;                      // antennas per workgroup
     auto lds_of = [&](int a) { return sizeof(double2) * ((size_t)a * (dp.n_sub + 1) + dp.n_sub / 2); };
     while (na > 1 && lds_of(na) > 150 * 1024) --na;
     const size_t lds = lds_of(na);
     if (lds > 150 * 1024) return -1;
     const int n_chunks = (dp.n_t + na - 1) / na;
+    dp.na_wg = na;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(detect_count_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(detect_count_kernel, dim3(dp.n_frames * n_chunks), dim3(64 * na), lds, stream, dp);
+    hipLaunchKernelGGL(detect_count_kernel, dim3(dp.n_frames * n_chunks), dim3(32 * na < 64 ? 64 : 32 * na), lds, stream, dp);
     return (int)hipGetLastError();
 }
 

@@ -351,6 +351,30 @@ def test_detect_count_vs_oracle(amd, golden):
     np.testing.assert_array_equal(nb.cpu().numpy(), [F * cfg.n_sub * cfg.m * cfg.n_t] * 2)
 
 
+@pytest.mark.parametrize("n_sub,n_t,m", [(64, 4, 4), (128, 2, 2), (32, 1, 6), (256, 3, 4), (2048, 5, 2)])
+def test_detect_count_shapes(amd, n_sub, n_t, m):
+    """Even and odd log2 N (paired radix-2 stages + a lone last stage), 1..5 antennas (N=2048 x 5
+    needs two workgroups per frame), 4/16/64-QAM: spectrum vs numpy FFT, counts bit-exact."""
+    _, _, batched = amd
+    rs = np.random.RandomState(n_sub + n_t)
+    B, F = 7, 3
+    const = eo.unit_qam(m)
+    bits = rs.randint(0, 2, (B, n_sub * m, n_t)).astype(np.uint8)
+    p_i = np.array([0.7, 1.3, 2.1])
+    bank = batched.ReservoirBank(2, 2, 2, np.zeros((2, 2)), np.zeros((2, 2)), np.zeros((2, 2)))
+    y = rs.randn(B, n_sub, 2 * n_t) * np.sqrt(n_sub)
+    err, nb, xh = bank.detect_count(y, bits, p_i, F, n_sub, n_t, m, want_xhat=True)
+    want = np.zeros(3, dtype=np.int64)
+    for i in range(B):
+        x_t = y[i, :, 0::2] + 1j * y[i, :, 1::2]                                  # [N, n_t]
+        x_hat = np.fft.fft(x_t, axis=0) / n_sub / np.sqrt(p_i[i // F])
+        got = xh[i].cpu().numpy().view(np.complex128).reshape(n_sub, n_t)
+        assert rel_err(got, x_hat) < 1e-12
+        want[i // F] += eo.count_bit_errors(bits[i], eo.hard_bits(got, const, m))
+    np.testing.assert_array_equal(err.cpu().numpy(), want)
+    np.testing.assert_array_equal(nb.cpu().numpy(), [3 * n_sub * m * n_t, 3 * n_sub * m * n_t, n_sub * m * n_t])
+
+
 def test_counter_noise_statistics(amd):
     """The counter generator is zero-mean uniform of width `noise`; outputs stay within the
     perturbation the reference's own state noise causes (statistical, not bit-equal)."""
