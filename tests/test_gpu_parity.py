@@ -166,7 +166,7 @@ def test_ragged_batch_and_groups(amd, precision):
 
 @pytest.mark.parametrize("n_res,n_in,n_out,G,F", [(256, 16, 8, 5, 75), (512, 16, 8, 5, 75), (1024, 16, 8, 5, 75),
                                                   (512, 4, 4, 5, 75), (512, 2, 2, 5, 75), (512, 16, 8, 2, 301)])
-@pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3)])
+@pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3), ("tensor", 1e-3)])
 def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res, n_in, n_out, G, F):
     """The fp16 predict kernel of 8-wave tilings (N_res 256 / 512 / 1024: 128, 128 and 64 frames per
     tile) runs the skewed wave schedule; ESN_SKEW=0 selects the in-step schedule of the same arithmetic.  Ragged groups (tiles straddle groups and padding slots), short
@@ -185,6 +185,10 @@ def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res,
     u = rs.randn(G * F - 9, t_in, n_in)                       # last group is short
     x0, y0 = rs.randn(G, n_res) * 0.1, rs.randn(G, n_out) * 0.1
     kw = dict(T=t, transient=tr, precision="f16", x0=x0, y0=y0, noise_mode=noise_mode, seed=5)
+    if noise_mode == "tensor":
+        if (n_res, n_in) != (512, 16):
+            pytest.skip("tensor noise: one shape is enough")
+        kw["noise_u"] = rs.rand(u.shape[0], t, n_res)
     assert os.environ.get("ESN_SKEW") is None
     skew = bank.predict(u, F, **kw).cpu().numpy()
     os.environ["ESN_SKEW"] = "0"
