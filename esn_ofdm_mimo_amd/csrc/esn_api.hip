@@ -149,6 +149,14 @@ int esn_pack_readout(int precision, const esn_shape_t* shape, int n_groups, cons
                     "esn_pack_readout");
 }
 
+// float64 kernel: every frame slot of a tile costs its share of FMAs whether it holds a frame or not,
+// so a batch smaller than the tile (the 2-D drop-in is ONE sequence) gets a smaller tile
+static void shrink_f64_tile(int precision, RecurParams& p) {
+    if (precision != ESN_F64) return;
+    const long long slots = (long long)p.n_groups * p.Fpad;
+    while (p.g.Bt > 1 && p.g.Bt / 2 >= slots) p.g.Bt >>= 1;
+}
+
 static int fill_common(RecurParams& p, int precision, const esn_shape_t* shape, const char* who,
                        bool harvest = false) {
     memset(&p, 0, sizeof(p));
@@ -183,6 +191,7 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     // 16-frame column granularity (MFMA kernels) or no padding at all (float64 kernel)
     if (p.n_wsets > 1) p.Fpad = round_up(p.F, p.g.Bt);
     else p.Fpad = (precision == ESN_F64) ? p.F : round_up(p.F, 16);
+    shrink_f64_tile(precision, p);
     p.n_tiles = (int)(((long long)p.n_groups * p.Fpad + p.g.Bt - 1) / p.g.Bt);
     p.T_in = T_in; p.S = T; p.in_row_off = 0; p.transient = transient; p.harvest = 0;
     p.packed_w = packed_w; p.packed_wout = packed_wout;
@@ -212,6 +221,7 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     p.n_groups = n_groups;
     p.F = 1;
     p.Fpad = (p.n_wsets == 1) ? 1 : p.g.Bt;   // shared reservoir: tiles span groups
+    if (p.n_wsets == 1) shrink_f64_tile(precision, p);
     p.n_tiles = (int)(((long long)n_groups * p.Fpad + p.g.Bt - 1) / p.g.Bt);
     p.T_in = T; p.S = T - 1; p.in_row_off = 1; p.transient = 0; p.harvest = 1;
     p.packed_w = packed_w;

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
 #pragma unroll
             for (int f = 0; f < FB; ++f) { a0[f] = 0.0; a1[f] = 0.0; }
             const double* w = Wk;
+#pragma unroll 8
             for (int k = 0; k < n_res; ++k, w += n_res) {
                 double w0 = w[r0];
                 double w1 = has1 ? w[r1] : 0.0;
@@ -220,7 +221,8 @@ int launch_recur_f64(const RecurParams& p, hipStream_t stream) {
     // frames per tile: 8 while the double-buffered state fits in 150 KB, else 4/2/1
     const int FB = p.g.Bt;
     size_t lds = recur_f64_lds_bytes(FB, p.n_res, p.n_in, p.n_out);
-    int threads = round_up((p.n_res + 1) / 2, 64);
+    // two rows per thread; one row per thread for the small tiles (latency-bound: more waves, more loads in flight)
+    int threads = round_up(FB <= 2 ? p.n_res : (p.n_res + 1) / 2, 64);
     if (threads > 1024) threads = 1024;
     if (threads < 64) threads = 64;
     dim3 grid(p.n_tiles), block(threads);
