@@ -1,0 +1,38 @@
+"""bench.py prints ONE JSON line with the fields the driver and the judge read (task contract,
+section 4 of the tier framing): metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+higher_is_better / scaling / vs_baseline / dtype / data / config.workload + roofline + cpu_baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_small_run():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--blocks", "64", "--cpu-blocks", "1"], capture_output=True, text=True, cwd=ROOT,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["unit"] == "OFDM symbols/s" and d["value"] > 1e5
+    # value = frames per step * steps / wall time
+    assert abs(d["value"] - d["config"]["frames_per_step"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("mfma", "hbm") and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"]
+    # the detector works: BER of the 4x8 ESN at 12 dB is ~0.23 for both the GPU and the oracle sample
+    assert 0.15 < d["ber"] < 0.30
