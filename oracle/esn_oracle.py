@@ -19,6 +19,7 @@ Reference citations (file:line are relative to the reference tree):
   * fit (harvest + pinv) ....... libs/pyESN.py:154-216
   * predict .................... libs/pyESN.py:218-255
   * frame<->ESN adapter ........ libs/helper_mimo_esn_generic.py:5-86
+  * legacy 2x2 adapter ......... libs/HelpFunc.py:64-187
   * rx packing at inference .... system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:433-436
   * output reconstruction ...... system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:47-58
   * FFT + power de-scale ....... system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:439-441
@@ -34,7 +35,7 @@ import numpy as np
 
 __all__ = [
     "broadcast_arg", "draw_weights", "OracleESN", "pack_delay_io",
-    "train_mimo_esn", "pack_rx", "outputs_to_time_signals", "time_to_freq",
+    "train_mimo_esn", "train_mimo_esn_legacy", "pack_rx", "outputs_to_time_signals", "time_to_freq",
     "unit_qam", "bit_labels_lsb_first", "hard_bits", "count_bit_errors",
     "detect_frame",
 ]
@@ -234,6 +235,58 @@ def train_mimo_esn(esn, delay_flag, min_delay, max_delay, cp_len, n_sub, n_t,
     esn.fit(x_in, x_out, forget)
     delay = np.full(2 * n_t, int(d), dtype=int)
     return [x_in, x_out, esn, delay, idx, int(d), int(d), forget, float(nmse)]
+
+
+# --------------------------------------------------------------------------
+# a13: legacy 2x2 adapter (HelpFunc.py:64-187), DelayFlag == 0 branch
+# --------------------------------------------------------------------------
+def train_mimo_esn_legacy(esn, delay_flag, min_delay, max_delay, cp_len, n_sub, n_t, n_r, isi, y_cp, x_cp,
+                          echo=None):
+    """Restates HelpFunc.trainMIMOESN for DelayFlag == 0 (the only branch that runs: the other one
+    dies at np.zeros(shape, 1), HelpFunc.py:76).  Two receive and two transmit streams are
+    hard-wired (HelpFunc.py:112-122).  Delay table row j = [j, j, j, j] for j = 0..Max
+    (:97-99); each row: fit, predict on the training input, NMSE of the N+1-row slice against
+    x_CP[Isi-1:] (:124-152); then the row index is FORCED to 3 (:159), the NMSE vector is
+    printed (:161) and the ESN is fitted once more on row 3 (:166-182)."""
+    if delay_flag:
+        raise TypeError("Cannot interpret '1' as a data type")       # what np.zeros(shape, 1) raises
+    rows = max_delay + 1 - min_delay
+    lut = np.zeros((rows, 4), dtype=np.int32)
+    for j in range(0, max_delay + 1):
+        lut[j, :] = j
+    d_hi, d_lo = lut.max(axis=1), lut.min(axis=1)
+
+    def build(j):
+        t_pad = n_sub + d_hi[j] + cp_len
+        x_in = np.zeros((t_pad, n_t * 2))
+        x_out = np.zeros((t_pad, n_t * 2))
+        for rx in range(2):
+            x_in[:, 2 * rx] = np.append(y_cp[:, rx].real, np.zeros(d_hi[j]))
+            x_in[:, 2 * rx + 1] = np.append(y_cp[:, rx].imag, np.zeros(d_hi[j]))
+        span = n_sub + cp_len
+        for tx in range(2):
+            x_out[lut[j, 2 * tx]:lut[j, 2 * tx] + span, 2 * tx] = x_cp[:, tx].real
+            x_out[lut[j, 2 * tx + 1]:lut[j, 2 * tx + 1] + span, 2 * tx + 1] = x_cp[:, tx].imag
+        return x_in, x_out
+
+    nmse = np.zeros(rows)
+    ref = x_cp[isi - 1:, :]
+    for j in range(rows):
+        x_in, x_out = build(j)
+        forget = d_lo[j] + cp_len
+        esn.fit(x_in, x_out, forget)
+        pred = esn.predict(x_in, forget, continuation=False)
+        for tx in range(2):
+            a = lut[j, 2 * tx] - d_lo[j]
+            b = lut[j, 2 * tx + 1] - d_lo[j]
+            xh = pred[a:a + n_sub + 1, 2 * tx] + 1j * pred[b:b + n_sub + 1, 2 * tx + 1]
+            nmse[j] += np.linalg.norm(xh - ref[:, tx]) ** 2 / np.linalg.norm(ref[:, tx]) ** 2
+    pick = 3
+    (echo or print)(nmse)
+    x_in, x_out = build(pick)
+    forget = d_lo[pick] + cp_len
+    esn.fit(x_in, x_out, forget)
+    return [x_in, x_out, esn, lut[pick, :], pick, d_lo[pick], d_hi[pick], forget, np.amin(nmse)]
 
 
 # --------------------------------------------------------------------------

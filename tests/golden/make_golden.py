@@ -18,6 +18,10 @@ Cases:
   c4     N_res=512  4x8   N=128 CP=7 d=3  (helper + 16-frame detection batch)
   c4s    N_res=300  4x8   N=128           (driver default reservoir)
   c5     N_res=2048 4x8   N=128           (helper, W_out only + predictions)
+  mackey N_res=100  1 -> 1  2000-step teacher-forced fit on a constant input + 2000-step free run
+         (BASELINE configs[0]; the series comes from oracle/mackey_glass.py and is stored)
+  scan   N_res=100  2x2   N=128  trainMIMOESN_generic with DelayFlag=1 (delay scan, helper:66-81)
+  legacy N_res=100  2x2   N=128  HelpFunc.trainMIMOESN (7 fit+predict, forced d=3; HelpFunc.py:64-187)
 """
 import hashlib
 import os
@@ -36,6 +40,7 @@ from helper_mimo_esn_generic import trainMIMOESN_generic as ref_train  # noqa: E
 from HelpFunc import HelpFunc as RefHelp  # noqa: E402
 
 from oracle.ofdm_frames import LinkConfig, make_frame, tdlb_mimo_taps, exp_pdp_taps  # noqa: E402
+from oracle.mackey_glass import mackey_glass  # noqa: E402
 
 
 def digest(a):
@@ -170,9 +175,99 @@ def case_misc():
     save("misc", **out)
 
 
+def case_mackey():
+    """BASELINE configs[0]: the upstream pyESN demo the reference's results/mecky_glass.png.png
+    shows, at N_res=100 -- fit(ones, series) then predict(ones) with continuation=True, i.e. a free
+    run in which W_feedb*y is O(1).  Default noise (0.001) and noise=0."""
+    train, future = 2000, 2000
+    data = mackey_glass(train + future)
+    out = dict(series=data, trainlen=train, future=future, n_res=100, rho=1.5, seed=42)
+    for tag, noise in (("n1", 0.001), ("n0", 0.0)):
+        esn = ref_pyesn.ESN(n_inputs=1, n_outputs=1, n_reservoir=100, spectral_radius=1.5,
+                            noise=noise, random_state=42)
+        if tag == "n1":
+            out.update(weight_pins(esn))
+        out[tag + "_pred_train"] = esn.fit(np.ones(train), data[:train])
+        out[tag + "_W_out"] = esn.W_out.copy()
+        out[tag + "_laststate"] = esn.laststate.copy()
+        out[tag + "_lastoutput"] = esn.lastoutput.copy()
+        out[tag + "_free_run"] = esn.predict(np.ones(future))
+    save("mackey", **out)
+
+
+def _small_2x2(seed, ebno_db=12):
+    cfg = LinkConfig(n_t=2, n_r=2, n_sub=128)
+    rs = np.random.RandomState(seed + 11)
+    taps = exp_pdp_taps(cfg, rs)
+    pilot = make_frame(cfg, ebno_db, taps, rs)
+    n_in, n_out = 2 * cfg.n_r, 2 * cfg.n_t
+    kw = dict(spectral_radius=0.9, sparsity=0.1, input_shift=np.zeros(n_in),
+              input_scaling=cfg.input_scaling(ebno_db) * np.ones(n_in),
+              teacher_scaling=cfg.teacher_scale * np.ones(n_out), teacher_shift=np.zeros(n_out),
+              feedback_scaling=np.zeros(n_out))
+    return cfg, pilot, n_in, n_out, kw
+
+
+def case_scan():
+    """trainMIMOESN_generic with DelayFlag=1: fit+predict for every d in [Min, Max], keep the
+    lowest (mis-aligned) NMSE, final fit (helper:66-84)."""
+    seed, ebno = 41, 12
+    cfg, pilot, n_in, n_out, kw = _small_2x2(seed, ebno)
+    out = dict(seed=seed, ebno_db=ebno, pilot_y=pilot["y_cp"], pilot_x=pilot["x_cp"])
+    for tag, noise in (("n0", 0.0), ("n1", 0.001)):
+        esn = make_ref(n_in, n_out, 100, seed, noise, **kw)
+        ret = ref_train(esn, 1, cfg.min_delay, cfg.max_delay, cfg.cp, cfg.n_sub, cfg.n_t, cfg.n_r,
+                        cfg.isi, pilot["y_cp"], pilot["x_cp"])
+        esn_in, esn_out, esn, delay, d_idx, d_min, d_max, forget, nmse = ret
+        out.update({tag + "_esn_in": esn_in, tag + "_esn_out": esn_out, tag + "_delay": delay,
+                    tag + "_d_idx": d_idx, tag + "_d_min": d_min, tag + "_d_max": d_max,
+                    tag + "_forget": forget, tag + "_nmse": nmse, tag + "_W_out": esn.W_out.copy(),
+                    tag + "_laststate": esn.laststate.copy()})
+    save("scan", **out)
+
+
+def case_legacy():
+    """HelpFunc.trainMIMOESN (2x2 only): scans d = 0..Max with fit+predict each, prints the NMSE
+    vector, forces Delay_Idx = 3 and fits again (HelpFunc.py:101-187)."""
+    import contextlib
+    import io
+    seed, ebno = 43, 12
+    cfg, pilot, n_in, n_out, kw = _small_2x2(seed, ebno)
+    out = dict(seed=seed, ebno_db=ebno, pilot_y=pilot["y_cp"], pilot_x=pilot["x_cp"])
+    for tag, noise in (("n0", 0.0), ("n1", 0.001)):
+        esn = make_ref(n_in, n_out, 100, seed, noise, **kw)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ret = RefHelp.trainMIMOESN(esn, 0, cfg.min_delay, cfg.max_delay, cfg.cp, cfg.n_sub, cfg.n_t,
+                                       cfg.n_r, cfg.isi, pilot["y_cp"], pilot["x_cp"])
+        esn_in, esn_out, esn, delay, d_idx, d_min, d_max, forget, nmse = ret
+        out.update({tag + "_esn_in": esn_in, tag + "_esn_out": esn_out, tag + "_delay": delay,
+                    tag + "_d_idx": d_idx, tag + "_d_min": d_min, tag + "_d_max": d_max,
+                    tag + "_forget": forget, tag + "_nmse": nmse, tag + "_W_out": esn.W_out.copy(),
+                    tag + "_laststate": esn.laststate.copy(),
+                    tag + "_printed_values": np.array(buf.getvalue().replace("[", " ").replace("]", " ").split(),
+                                                      dtype=float)})
+    # the DelayFlag != 0 branch of the legacy trainer is broken (np.zeros(shape, 1): HelpFunc.py:76)
+    try:
+        RefHelp.trainMIMOESN(make_ref(n_in, n_out, 100, seed, 0.0, **kw), 1, cfg.min_delay, cfg.max_delay, cfg.cp,
+                             cfg.n_sub, cfg.n_t, cfg.n_r, cfg.isi, pilot["y_cp"], pilot["x_cp"])
+        out["flag1_error"] = np.array("")
+    except Exception as e:          # noqa: BLE001
+        out["flag1_error"] = np.array(type(e).__name__)
+    save("legacy", **out)
+
+
 def main():
+    only = set(sys.argv[1:])          # e.g. `make_golden.py mackey scan` regenerates just those
+    if only:
+        for name in only:
+            globals()["case_" + name]()
+        return
     case_constellation()
     case_misc()
+    case_mackey()
+    case_scan()
+    case_legacy()
     case_plain("tiny", 3, 2, 8, 12, seed=42, transient=2,
                kw=dict(spectral_radius=0.9, sparsity=0.25, input_scaling=[0.3, 0.2, 0.1],
                        input_shift=[0.0, 0.1, -0.1], teacher_scaling=0.5, teacher_shift=0.05))
