@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("ESN_HIP_LIB") or os.path.join(_PKG, "libesn_hip.so") 
 F64, F32, F16, BF16 = 0, 1, 2, 3
 PRECISIONS = {"f64": F64, "f32": F32, "f16": F16, "bf16": BF16}
 NOISE_NONE, NOISE_TENSOR, NOISE_COUNTER = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Shape(C.Structure):
@@ -25,6 +25,7 @@ _vp, _dp, _ip = C.c_void_p, C.c_void_p, C.c_void_p   # device pointers travel as
 SIGNATURES = {
     "esn_last_error": (C.c_char_p, []),
     "esn_abi_version": (C.c_int, []),
+    "esn_debug_set": (C.c_int, [C.c_char_p, C.c_char_p]),
     "esn_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.c_char_p, C.c_int]),
     "esn_tile_frames": (C.c_int, [C.c_int, C.POINTER(Shape)]),
@@ -106,6 +107,11 @@ def require_gpu():
 def stream_handle():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def debug_set(key, value):
+    """Tuning knob of the library (benchmarks / A-B tests): see esn_debug_set in include/esn_hip.h."""
+    check(load().esn_debug_set(key.encode(), None if value is None else str(value).encode()), "esn_debug_set")
 
 
 def device_info():

@@ -3,6 +3,7 @@
 // the thread-local error string -- every call is capturable into a hipGraph.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string.h>
 #include "esn_common.h"
@@ -46,6 +47,28 @@ int launch_detect_count(const DetectParams& dp, hipStream_t stream);
 using namespace esn;
 
 static thread_local char g_err[512] = "";
+
+namespace esn {
+static bool parse3(const char* v, int (&out)[3]) {
+    int a, b, c;
+    if (v && sscanf(v, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { out[0] = a; out[1] = b; out[2] = c; return true; }
+    out[0] = out[1] = out[2] = 0;
+    return false;
+}
+Knobs& knobs() {
+    static Knobs k = [] {
+        Knobs x;
+        const char* v = getenv("ESN_SKEW");
+        x.skew = (v && v[0] == '0') ? 0 : 1;
+        parse3(getenv("ESN_MFMA_GEOM"), x.geom16);
+        parse3(getenv("ESN_MFMA_GEOM_F32"), x.geom32);
+        v = getenv("ESN_CHOL_SKIP");
+        x.chol_skip = v ? atoi(v) : 0;
+        return x;
+    }();
+    return k;
+}
+}  // namespace esn
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -91,7 +114,17 @@ extern "C" {
 
 const char* esn_last_error(void) { return g_err; }
 
-int esn_abi_version(void) { return 4; }
+int esn_abi_version(void) { return 5; }
+
+int esn_debug_set(const char* key, const char* value) {
+    if (!key) return fail(-1, "esn_debug_set: null key");
+    Knobs& k = knobs();
+    if (!strcmp(key, "skew")) { k.skew = (value && value[0] == '0') ? 0 : 1; return 0; }
+    if (!strcmp(key, "mfma_geom")) { parse3(value, k.geom16); return 0; }
+    if (!strcmp(key, "mfma_geom_f32")) { parse3(value, k.geom32); return 0; }
+    if (!strcmp(key, "chol_skip")) { k.chol_skip = value ? atoi(value) : 0; return 0; }
+    return fail(-1, "esn_debug_set: unknown key '%s'", key);
+}
 
 int esn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* arch_name, int arch_name_len) {
     int dev = 0;

@@ -143,6 +143,18 @@ __device__ __forceinline__ int slot_frame(const RecurParams& p, int slot, int& g
 
 inline __host__ __device__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Tuning / diagnostic knobs (benchmarks and A/B tests only).  Read ONCE per process from the
+// environment (ESN_SKEW, ESN_MFMA_GEOM, ESN_MFMA_GEOM_F32, ESN_CHOL_SKIP) and changed afterwards only
+// through the debug entry point esn_debug_set (esn_api.hip) -- never re-read per launch.  None of
+// them changes a packed image: the weight image depends on (precision, n_res, n_in, n_out) alone.
+struct Knobs {
+    int skew;              // 1 (default): skewed schedule where it applies; 0: in-step schedule
+    int geom16[3];         // fp16/bf16 predict tiling override {NW, MT, NT}; {0,0,0} = table
+    int geom32[3];         // float32 predict tiling override
+    int chol_skip;         // bit mask of Cholesky-solve phases to drop (tools/time_chol.py)
+};
+Knobs& knobs();
+
 // Bijective XCD-aware remap (guide T1): consecutive logical tiles land on the
 // same XCD so tiles of one weight set share that XCD's L2.  Speed only.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

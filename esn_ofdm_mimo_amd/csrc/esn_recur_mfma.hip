@@ -30,11 +30,13 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
         else if (n_res <= 2048) { NW = 16; MT = 4; NT = 1; }
         else return false;
     }
-    // tuning knob (benchmarks only): ESN_MFMA_GEOM="NW,MT,NT" overrides the fp16/bf16 predict table
+    // The packed weight image is a function of (Mp, Kp) only, and Mp comes from the table above: pack,
+    // harvest and predict always agree on it.  A tuning override ("NW,MT,NT", benchmarks only; knobs())
+    // may re-cut the same Mp rows into other waves / tiles but is IGNORED when it would change Mp.
+    const int Mp_table = 32 * MT * NW;
     if (!harvest) {
-        const char* ov = getenv(es == 2 ? "ESN_MFMA_GEOM" : "ESN_MFMA_GEOM_F32");
-        int a, b, c;
-        if (ov && sscanf(ov, "%d,%d,%d", &a, &b, &c) == 3 && 32 * a * b >= n_res) { NW = a; MT = b; NT = c; }
+        const int* ov = (es == 2) ? knobs().geom16 : knobs().geom32;
+        if (ov[0] > 0 && 32 * ov[0] * ov[1] == Mp_table) { NW = ov[0]; MT = ov[1]; NT = ov[2]; }
     }
     // harvest: one pilot per trained ESN -> few sequences; a 32-frame tile spreads them over more CUs
     if (harvest && n_res > 256 && n_res <= 512) { NW = 8; MT = 2; NT = 1; }
@@ -53,12 +55,11 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
     // skewed wave schedule (predict): 8-wave fp16/bf16 tilings with one readout image and state
     // k-groups that split into two even halves; ESN_SKEW=0 keeps the in-step schedule (A/B runs)
     {
-        const char* sk = getenv("ESN_SKEW");
         const int nkgS = g->Mp * es / 32;
         const int n_uf = g->Kp * es / 32 - nkgS;
         g->skew = (!harvest && es == 2 && NW == 8 && (NT == 2 || NT == 4) && g->ro_parts == 1 && nkgS % 8 == 0 && n_uf <= 4 &&
                    (n_in == 2 || n_in == 4 || n_in == 8 || n_in == 16) &&
-                   !(sk && sk[0] == '0')) ? 1 : 0;
+                   knobs().skew) ? 1 : 0;
     }
     // Zt image + the small frame / scale tables behind it (esn_recur_mfma_impl.h); the skewed schedule
     // stages the raw input rows in one 1 KB slot per DMA instruction (two per 16-frame tile)

@@ -569,7 +569,7 @@ int launch_readout_chol(const double* E, const float* E32, const double* D, int 
     sp.cols = cols; sp.n_out = n_out; sp.t_scale = t_scale; sp.t_shift = t_shift;
     sp.W_out = W_out; sp.status = status; sp.work = nullptr; sp.work_stride = 0;
     sp.wide = rows < cols; sp.m = sp.wide ? cols : rows; sp.n = n;
-    { const char* sk = getenv("ESN_CHOL_SKIP"); sp.skip = sk ? atoi(sk) : 0; }
+    sp.skip = knobs().chol_skip;
     const size_t lds = sizeof(double) * ((size_t)CH_NP * CH_LD + (size_t)n_out * CH_NP);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(readout_chol_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

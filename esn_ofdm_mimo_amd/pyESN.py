@@ -112,27 +112,20 @@ class ESN:
         self._bank.noise = float(self.noise)
         return self._bank
 
-    # ---- host-side scalings kept for API compatibility (pyESN.py:127-152) -------
-    def _scale_inputs(self, inputs):
-        if self.input_scaling is not None:
-            inputs = np.dot(inputs, np.diag(self.input_scaling))
-        if self.input_shift is not None:
-            inputs = inputs + self.input_shift
-        return inputs
-
+    # ---- teacher scaling of the few host-side values fit() returns (pyESN.py:137-152) --------
     def _scale_teacher(self, teacher):
-        if self.teacher_scaling is not None:
-            teacher = teacher * self.teacher_scaling
-        if self.teacher_shift is not None:
-            teacher = teacher + self.teacher_shift
-        return teacher
+        scale = 1.0 if self.teacher_scaling is None else self.teacher_scaling
+        shift = 0.0 if self.teacher_shift is None else self.teacher_shift
+        return teacher * scale + shift
 
     def _unscale_teacher(self, teacher_scaled):
-        if self.teacher_shift is not None:
-            teacher_scaled = teacher_scaled - self.teacher_shift
-        if self.teacher_scaling is not None:
-            teacher_scaled = teacher_scaled / self.teacher_scaling
-        return teacher_scaled
+        scale = 1.0 if self.teacher_scaling is None else self.teacher_scaling
+        shift = 0.0 if self.teacher_shift is None else self.teacher_shift
+        return (teacher_scaled - shift) / scale
+
+    def _report(self, text):
+        if not self.silent:
+            print(text)
 
     # ---- fit (pyESN.py:154-216) --------------------------------------------------
     def fit(self, inputs, outputs, transient=0, inspect=False):
@@ -145,16 +138,13 @@ class ESN:
         if inputs.ndim != 2 or outputs.ndim != 2:
             raise ValueError("fit takes one training sequence: inputs [T, n_in], outputs [T, n_out]")
         bank = self._get_bank()
-        torch = bank.torch
         n = inputs.shape[0]
         # the reference draws rand(n_reservoir) once per update, noise or not (pyESN.py:124-125)
         noise_u = self.random_state_.rand(max(n - 1, 0), self.n_reservoir)
-        if not self.silent:
-            print("harvesting states...")
+        self._report("harvesting states...")
         E = bank.harvest(inputs[None], outputs[None], precision="f64",
                          noise_mode="tensor" if self.noise else "none", noise_u=noise_u[None])
-        if not self.silent:
-            print("fitting...")
+        self._report("fitting...")
         W_out, status = bank.solve(E, outputs[None], transient)
         bank.set_readout(W_out)
         self.fit_status = int(status[0].item())
@@ -163,17 +153,15 @@ class ESN:
         self.laststate = ext[-1, :self.n_reservoir].cpu().numpy()
         self.lastinput = inputs[-1, :]
         self.lastoutput = self._scale_teacher(outputs)[-1, :]
-        if inspect:
-            from matplotlib import pyplot as plt
-            ext_h = ext.cpu().numpy()
-            plt.figure(figsize=(ext_h.shape[0] * 0.0025, ext_h.shape[1] * 0.01))
-            plt.imshow(ext_h.T, aspect='auto', interpolation='nearest')
-            plt.colorbar()
-        if not self.silent:
-            print("training error:")
-        pred_train = self._unscale_teacher(torch.matmul(ext, W_out[0].T).cpu().numpy())
-        if not self.silent:
-            print(np.sqrt(np.mean((pred_train - outputs) ** 2)))
+        if inspect:                     # the reference's state picture (pyESN.py:200-207), from device memory
+            from matplotlib import pyplot
+            picture = ext.cpu().numpy().T
+            pyplot.figure(figsize=(picture.shape[1] * 0.0025, picture.shape[0] * 0.01))
+            pyplot.imshow(picture, aspect="auto", interpolation="nearest")
+            pyplot.colorbar()
+        pred_train = self._unscale_teacher(bank.torch.matmul(ext, W_out[0].T).cpu().numpy())
+        self._report("training error:")
+        self._report(np.sqrt(np.mean((pred_train - outputs) ** 2)))
         return pred_train
 
     # ---- predict (pyESN.py:218-255) ------------------------------------------------

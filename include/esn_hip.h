@@ -4,7 +4,8 @@
  * Every entry point is extern "C", takes plain pointers and sizes, returns an int
  * status (0 = ok, <0 = error; text via esn_last_error()) and launches its work
  * on the caller's hipStream_t (passed as void*; NULL = default stream).  No
- * hidden global state besides a thread-local error string; no exceptions cross
+ * hidden global state besides a thread-local error string and the tuning knobs
+ * of esn_debug_set (below; never needed by a user); no exceptions cross
  * the boundary.  All array arguments are DEVICE pointers unless a name ends in
  * `_host`.  Arrays keep the reference's own row-major float64 layouts so a
  * binding needs no repacking:
@@ -73,6 +74,16 @@ const char* esn_last_error(void);
 
 /* ABI version (bumped on any signature change). */
 int esn_abi_version(void);
+
+/* Tuning / diagnostic knobs for benchmarks and A/B tests (no counterpart in the reference).  The
+ * library reads ESN_SKEW, ESN_MFMA_GEOM, ESN_MFMA_GEOM_F32 and ESN_CHOL_SKIP from the environment
+ * ONCE, at its first call, as initial values; afterwards only this call changes them:
+ *   "skew"          "0" = in-step schedule for the fp16/bf16 predict kernel, else skewed (default)
+ *   "mfma_geom"     "NW,MT,NT" re-cuts the fp16/bf16 predict tiling; ignored unless 32*NW*MT equals
+ *   "mfma_geom_f32" the table's padded row count, so a packed image never goes stale; NULL = table
+ *   "chol_skip"     bit mask of Cholesky-solve phases to drop (timing only, wrong results)
+ * Returns 0, or -1 for an unknown key. */
+int esn_debug_set(const char* key, const char* value);
 
 /* Device facts used for roofline reporting (any pointer may be NULL). */
 int esn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz,

@@ -169,7 +169,7 @@ def test_ragged_batch_and_groups(amd, precision):
 @pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3), ("tensor", 1e-3)])
 def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res, n_in, n_out, G, F):
     """The fp16 predict kernel of 8-wave tilings (N_res 256 / 512 / 1024: 128, 128 and 64 frames per
-    tile) runs the skewed wave schedule; ESN_SKEW=0 selects the in-step schedule of the same arithmetic.  Ragged groups (tiles straddle groups and padding slots), short
+    tile) runs the skewed wave schedule; the debug knob skew=0 selects the in-step schedule of the same arithmetic.  Ragged groups (tiles straddle groups and padding slots), short
     inputs (rows past T_in are zeros), per-group read-outs, initial state / feedback, both noise modes."""
     import os
     _, _, batched = amd
@@ -189,13 +189,14 @@ def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res,
         if (n_res, n_in) != (512, 16):
             pytest.skip("tensor noise: one shape is enough")
         kw["noise_u"] = rs.rand(u.shape[0], t, n_res)
+    from esn_ofdm_mimo_amd import _lib
     assert os.environ.get("ESN_SKEW") is None
     skew = bank.predict(u, F, **kw).cpu().numpy()
-    os.environ["ESN_SKEW"] = "0"
+    _lib.debug_set("skew", "0")
     try:
         plain = bank.predict(u, F, **kw).cpu().numpy()
     finally:
-        del os.environ["ESN_SKEW"]
+        _lib.debug_set("skew", "1")
     assert skew.shape == plain.shape == (G * F - 9, t - tr, n_out)
     # same weights, same noise draws; only the summation order of the read-out and the rounding of
     # the noise addition (packed half: one more rounding to fp16 per state) differ
