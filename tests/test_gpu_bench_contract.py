@@ -33,6 +33,14 @@ def test_bench_line_small_run():
     assert r["bound"] in ("mfma", "hbm") and r["unit"] == "TFLOP/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
+    assert set(c["legs"]) == {"single_thread", "default_blas_threads", "process_per_core"}
+    assert c["legs"]["single_thread"]["cores"] == 1 and c["host_cpu"] and c["host_cores_visible"] >= c["cores"]
+    # reference-precision and reference-faithful sub-records ride in the same line (N=1)
+    for prec, peak in (("f32", 157.3), ("f64", 78.6)):
+        p_ = d["precisions"][prec]
+        assert p_["value"] > 0 and p_["peak"] == peak and abs(p_["frac"] - p_["achieved_tflops"] / peak) < 1e-9
+        assert 0.15 < p_["ber"] < 0.30
+    assert d["reservoirs"]["per_block"]["value"] > 0 and 0.15 < d["reservoirs"]["per_block"]["ber"] < 0.30
     # the detector works: BER of the 4x8 ESN at 12 dB is ~0.23 for both the GPU and the oracle sample
     assert 0.15 < d["ber"] < 0.30
