@@ -12,12 +12,17 @@ namespace esn {
 // esn_recur_f64.hip
 int launch_recur_f64(const RecurParams& p, hipStream_t stream);
 size_t recur_f64_lds_bytes(int FB, int n_res, int n_in, int n_out);
+// esn_recur_f64_mfma.hip
+bool f64_mfma_geometry(int n_res, int n_in, int n_out, bool harvest, Geometry* g);
+int launch_recur_f64_mfma(const RecurParams& p, hipStream_t stream);
 // esn_recur_mfma.hip
 bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
 // esn_pack.hip
 size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
 size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
+size_t f64_w_offset(int n_res, int n_in, int n_out);
+size_t f64_wout_offset(int n_res, int n_in, int n_out);
 int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g, const double* W,
                         const double* Win, const double* Wfb, void* packed, hipStream_t stream);
 int launch_pack_readout(int precision, const esn_shape_t* sh, const Geometry& g, int n_groups,
@@ -64,6 +69,8 @@ Knobs& knobs() {
         parse3(getenv("ESN_MFMA_GEOM_F32"), x.geom32);
         v = getenv("ESN_CHOL_SKIP");
         x.chol_skip = v ? atoi(v) : 0;
+        v = getenv("ESN_F64_MFMA");
+        x.f64_mfma = (v && v[0] == '0') ? 0 : 1;
         return x;
     }();
     return k;
@@ -95,6 +102,12 @@ static bool geometry_for(int precision, const esn_shape_t* s, Geometry* g, bool 
         int fb = 8;
         while (fb > 1 && recur_f64_lds_bytes(fb, s->n_res, s->n_in, s->n_out) > 150 * 1024) fb >>= 1;
         if (recur_f64_lds_bytes(fb, s->n_res, s->n_in, s->n_out) > 160 * 1024) return false;
+        // the matrix-pipe kernel where it fits (predict AND harvest must fit: one packed image serves both)
+        Geometry gp, gh;
+        memset(&gp, 0, sizeof(gp)); memset(&gh, 0, sizeof(gh));
+        if (f64_mfma_geometry(s->n_res, s->n_in, s->n_out, false, &gp) &&
+            f64_mfma_geometry(s->n_res, s->n_in, s->n_out, true, &gh))
+            *g = harvest ? gh : gp;
         g->Bt = fb;
         return true;
     }
@@ -123,6 +136,7 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "mfma_geom")) { parse3(value, k.geom16); return 0; }
     if (!strcmp(key, "mfma_geom_f32")) { parse3(value, k.geom32); return 0; }
     if (!strcmp(key, "chol_skip")) { k.chol_skip = value ? atoi(value) : 0; return 0; }
+    if (!strcmp(key, "f64_mfma")) { k.f64_mfma = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }
 
@@ -190,6 +204,12 @@ static void shrink_f64_tile(int precision, RecurParams& p) {
     while (p.g.Bt > 1 && p.g.Bt / 2 >= slots) p.g.Bt >>= 1;
 }
 
+// float64: the matrix-pipe kernel for batches (more slots than one vector-ALU tile holds), the
+// vector-ALU kernel for the 2-D drop-in's single sequence and for shapes the MFMA tiling does not cover
+static bool use_f64_mfma(int precision, const RecurParams& p, long long sequences) {
+    return precision == ESN_F64 && p.g.m64 && sequences > 8 && knobs().f64_mfma;
+}
+
 static int fill_common(RecurParams& p, int precision, const esn_shape_t* shape, const char* who,
                        bool harvest = false) {
     memset(&p, 0, sizeof(p));
@@ -200,6 +220,8 @@ static int fill_common(RecurParams& p, int precision, const esn_shape_t* shape, 
     p.n_wsets = shape->n_wsets;
     p.wset_stride = packed_w_bytes(precision, p.n_res, p.n_in, p.n_out, p.g);
     p.wout_stride = packed_wout_bytes(precision, p.n_res, p.n_in, p.n_out, p.g);
+    p.w64_off = f64_w_offset(p.n_res, p.n_in, p.n_out);
+    p.wo64_off = f64_wout_offset(p.n_res, p.n_in, p.n_out);
     return 0;
 }
 
@@ -222,10 +244,12 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     p.n_groups = (n_frames + frames_per_group - 1) / frames_per_group;
     // slots per group: whole tiles when each group has its own weight set, else the readout's
     // 16-frame column granularity (MFMA kernels) or no padding at all (float64 kernel)
-    if (p.n_wsets > 1) p.Fpad = round_up(p.F, p.g.Bt);
-    else p.Fpad = (precision == ESN_F64) ? p.F : round_up(p.F, 16);
-    shrink_f64_tile(precision, p);
-    p.n_tiles = (int)(((long long)p.n_groups * p.Fpad + p.g.Bt - 1) / p.g.Bt);
+    const bool m64 = use_f64_mfma(precision, p, n_frames);
+    const int tile = m64 ? p.g.Bt64 : p.g.Bt;
+    if (p.n_wsets > 1) p.Fpad = round_up(p.F, tile);
+    else p.Fpad = (precision == ESN_F64 && !m64) ? p.F : round_up(p.F, 16);
+    if (!m64) shrink_f64_tile(precision, p);
+    p.n_tiles = (int)(((long long)p.n_groups * p.Fpad + (m64 ? tile : p.g.Bt) - 1) / (m64 ? tile : p.g.Bt));
     p.T_in = T_in; p.S = T; p.in_row_off = 0; p.transient = transient; p.harvest = 0;
     p.packed_w = packed_w; p.packed_wout = packed_wout;
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
@@ -233,8 +257,9 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
     p.Y = Y;
     ESN_SET_STAMPS(p);
-    int e = (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
-                                   : launch_recur_mfma(precision, p, (hipStream_t)stream);
+    int e = m64 ? launch_recur_f64_mfma(p, (hipStream_t)stream)
+            : (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
+                                     : launch_recur_mfma(precision, p, (hipStream_t)stream);
     return hip_fail(e, "esn_predict_batch");
 }
 
@@ -253,9 +278,11 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     p.n_frames = n_groups;
     p.n_groups = n_groups;
     p.F = 1;
-    p.Fpad = (p.n_wsets == 1) ? 1 : p.g.Bt;   // shared reservoir: tiles span groups
-    if (p.n_wsets == 1) shrink_f64_tile(precision, p);
-    p.n_tiles = (int)(((long long)n_groups * p.Fpad + p.g.Bt - 1) / p.g.Bt);
+    const bool m64 = use_f64_mfma(precision, p, n_groups);
+    const int tile = m64 ? p.g.Bt64 : p.g.Bt;
+    p.Fpad = (p.n_wsets == 1) ? 1 : tile;   // shared reservoir: tiles span groups
+    if (p.n_wsets == 1 && !m64) shrink_f64_tile(precision, p);
+    p.n_tiles = (int)(((long long)n_groups * p.Fpad + (m64 ? tile : p.g.Bt) - 1) / (m64 ? tile : p.g.Bt));
     p.T_in = T; p.S = T - 1; p.in_row_off = 1; p.transient = 0; p.harvest = 1;
     p.packed_w = packed_w;
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
@@ -263,8 +290,9 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
     p.E = E; p.E32 = E32;
     ESN_SET_STAMPS(p);
-    int e = (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
-                                   : launch_recur_mfma(precision, p, (hipStream_t)stream);
+    int e = m64 ? launch_recur_f64_mfma(p, (hipStream_t)stream)
+            : (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
+                                     : launch_recur_mfma(precision, p, (hipStream_t)stream);
     return hip_fail(e, "esn_harvest_batch");
 }
 

@@ -22,6 +22,9 @@ struct Geometry {
     int ro_parts;    // readout images per group: 1, or 2 (hi + lo) for fp16/bf16 with n_out > 8
     int ro_fold;     // fp16/bf16, n_out <= 8: rows 0-7 = hi, rows 8-15 = lo of ONE 16-row image
     int skew;        // predict: the two waves of a SIMD run one third of a step apart (esn_recur_mfma_impl.h)
+    int m64;         // ESN_F64: 1 = the float64 matrix-pipe kernel (esn_recur_f64_mfma.hip) fits this shape;
+    int Bt64;        //          then Mp..Ks, MT, NT describe ITS tiling, Bt64 its frames per tile and Bt
+                     //          stays the tile of the vector-ALU kernel (esn_recur_f64.hip)
 };
 
 struct RecurParams {
@@ -44,6 +47,7 @@ struct RecurParams {
     int n_tiles;
     const void* packed_w;   size_t wset_stride;   // bytes per weight set
     const void* packed_wout; size_t wout_stride;  // bytes per group
+    size_t w64_off, wo64_off;                     // ESN_F64 images: byte offset of the MFMA-ordered copy
     const double* in_scale; const double* in_shift;
     const double* t_scale;  const double* t_shift;
     const double* U; const double* D;
@@ -152,6 +156,7 @@ struct Knobs {
     int geom16[3];         // fp16/bf16 predict tiling override {NW, MT, NT}; {0,0,0} = table
     int geom32[3];         // float32 predict tiling override
     int chol_skip;         // bit mask of Cholesky-solve phases to drop (tools/time_chol.py)
+    int f64_mfma;          // 1 (default): float64 batches run on the matrix pipe; 0: vector-ALU kernel (A/B tests)
 };
 Knobs& knobs();
 

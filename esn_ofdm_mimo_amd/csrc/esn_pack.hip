@@ -18,7 +18,7 @@ __device__ __forceinline__ double wext(const double* W, const double* Win, const
 // float64 image: K-major Wk[k][n_res], k over [W | W_in | W_fb] without padding.
 __global__ void pack_w_f64_kernel(const double* W, const double* Win, const double* Wfb,
                                   int n_res, int n_in, int n_out, int tf, int n_wsets,
-                                  double* out) {
+                                  size_t set_stride_bytes, char* out_base) {
     const size_t K = (size_t)n_res + n_in + n_out;
     const size_t per = K * n_res;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per * n_wsets;
@@ -32,7 +32,53 @@ __global__ void pack_w_f64_kernel(const double* W, const double* Win, const doub
         if (k < n_res) v = w[(size_t)r * n_res + k];
         else if (k < n_res + n_in) v = wi[(size_t)r * n_in + (k - n_res)];
         else v = tf ? wf[(size_t)r * n_out + (k - n_res - n_in)] : 0.0;
-        out[i] = v;
+        reinterpret_cast<double*>(out_base + ws * set_stride_bytes)[j] = v;
+    }
+}
+
+// float64 MFMA image (esn_recur_f64_mfma.hip): [row tile of 16][64-byte k-group][lane][2 doubles];
+// lane (r = lane & 15, q = lane >> 4) holds elements k = 8 kg + 2 q + {0, 1} of row 16 rt + r.
+__global__ void pack_w_f64_mfma_kernel(const double* W, const double* Win, const double* Wfb,
+                                       int n_res, int n_in, int n_out, int tf, int n_wsets,
+                                       Geometry g, size_t set_stride_bytes, size_t off_bytes, char* out_base) {
+    const int nkg = g.Kp / 8;
+    const size_t per = (size_t)g.Mp * g.Kp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per * n_wsets;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t ws = i / per, j = i % per;
+        const int e = (int)(j & 1); j >>= 1;
+        const int lane = (int)(j % 64); j /= 64;
+        const int kg = (int)(j % nkg);
+        const int rt = (int)(j / nkg);
+        const int row = rt * 16 + (lane & 15);
+        const int k = kg * 8 + 2 * (lane >> 4) + e;
+        double* out = reinterpret_cast<double*>(out_base + ws * set_stride_bytes + off_bytes);
+        out[i % per] = wext(W + ws * (size_t)n_res * n_res, Win + ws * (size_t)n_res * n_in,
+                            Wfb + ws * (size_t)n_res * n_out, n_res, n_in, n_out, tf, g.kin, g.kfb, row, k);
+    }
+}
+
+// float64 MFMA readout image per group: [64-byte k-group][lane][2 doubles], lane (o = lane & 15, q):
+// W_out[o][k], k = 8 kg + 2 q + {0, 1} in the kernel's k layout (state | inputs at kin | zeros).
+__global__ void pack_wout_f64_mfma_kernel(const double* Wout, int n_res, int n_in, int n_out, int n_groups,
+                                          Geometry g, size_t stride_bytes, size_t off_bytes, char* out_base) {
+    const int ncols = n_res + n_in;
+    const size_t per = (size_t)16 * g.Kp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per * n_groups;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t grp = i / per, j = i % per;
+        const int e = (int)(j & 1); j >>= 1;
+        const int lane = (int)(j % 64);
+        const int kg = (int)(j / 64);
+        const int o = lane & 15;
+        const int k = kg * 8 + 2 * (lane >> 4) + e;
+        double v = 0.0;
+        if (o < n_out) {
+            const double* wo = Wout + (grp * n_out + o) * ncols;
+            if (k < n_res) v = wo[k];
+            else if (k >= g.kin && k < g.kin + n_in) v = wo[n_res + (k - g.kin)];
+        }
+        reinterpret_cast<double*>(out_base + grp * stride_bytes + off_bytes)[i % per] = v;
     }
 }
 
@@ -124,14 +170,25 @@ __global__ __launch_bounds__(256) void pack_wout_mfma_kernel(const double* Wout,
     }
 }
 
+// ESN_F64 images hold the vector-ALU kernel's copy first and, when the matrix-pipe kernel fits the
+// shape (g.m64), its fragment-ordered copy behind it (16-byte aligned offset).
+size_t f64_w_offset(int n_res, int n_in, int n_out) {
+    return (sizeof(double) * (size_t)(n_res + n_in + n_out) * n_res + 15) / 16 * 16;
+}
+size_t f64_wout_offset(int n_res, int n_in, int n_out) {
+    return (sizeof(double) * (size_t)n_out * (n_res + n_in) + 15) / 16 * 16;
+}
+
 size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g) {
-    if (precision == ESN_F64) return sizeof(double) * (size_t)(n_res + n_in + n_out) * n_res;
+    if (precision == ESN_F64)
+        return f64_w_offset(n_res, n_in, n_out) + (g.m64 ? sizeof(double) * (size_t)g.Mp * g.Kp : 0);
     const int es = (precision == ESN_F32) ? 4 : 2;
     return (size_t)g.Mp * g.Kp * es;
 }
 
 size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g) {
-    if (precision == ESN_F64) return sizeof(double) * (size_t)n_out * (n_res + n_in);
+    if (precision == ESN_F64)
+        return f64_wout_offset(n_res, n_in, n_out) + (g.m64 ? sizeof(double) * (size_t)16 * g.Kp : 0);
     const int es = (precision == ESN_F32) ? 4 : 2;
     const int n_ot = (n_out + 15) / 16;
     return (size_t)g.ro_parts * n_ot * 16 * g.Kp * es + 16;
@@ -141,9 +198,14 @@ int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g,
                         const double* Win, const double* Wfb, void* packed, hipStream_t stream) {
     const int blocks = 1024, threads = 256;
     if (precision == ESN_F64) {
+        const size_t stride = packed_w_bytes(precision, sh->n_res, sh->n_in, sh->n_out, g);
         hipLaunchKernelGGL(pack_w_f64_kernel, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
                            sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets,
-                           reinterpret_cast<double*>(packed));
+                           stride, reinterpret_cast<char*>(packed));
+        if (g.m64)
+            hipLaunchKernelGGL(pack_w_f64_mfma_kernel, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
+                               sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g, stride,
+                               f64_w_offset(sh->n_res, sh->n_in, sh->n_out), reinterpret_cast<char*>(packed));
     } else if (precision == ESN_F32) {
         hipLaunchKernelGGL(pack_w_mfma_kernel<float>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
                            sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g,
@@ -166,8 +228,14 @@ int launch_pack_readout(int precision, const esn_shape_t* sh, const Geometry& g,
                         const double* Wout, void* packed, hipStream_t stream) {
     const size_t stride = packed_wout_bytes(precision, sh->n_res, sh->n_in, sh->n_out, g);
     if (precision == ESN_F64) {
-        hipError_t e = hipMemcpyAsync(packed, Wout, stride * n_groups, hipMemcpyDeviceToDevice, stream);
-        return (int)e;
+        const size_t plain = sizeof(double) * (size_t)sh->n_out * (sh->n_res + sh->n_in);
+        hipError_t e = hipMemcpy2DAsync(packed, stride, Wout, plain, plain, n_groups, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return (int)e;
+        if (g.m64)
+            hipLaunchKernelGGL(pack_wout_f64_mfma_kernel, dim3(n_groups < 1024 ? n_groups : 1024), dim3(256), 0, stream,
+                               Wout, sh->n_res, sh->n_in, sh->n_out, n_groups, g, stride,
+                               f64_wout_offset(sh->n_res, sh->n_in, sh->n_out), reinterpret_cast<char*>(packed));
+        return (int)hipGetLastError();
     }
     char* out = reinterpret_cast<char*>(packed);
     if (precision == ESN_F32)

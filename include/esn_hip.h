@@ -48,7 +48,8 @@ extern "C" {
 
 /* Arithmetic of the recurrence. */
 enum esn_precision {
-    ESN_F64 = 0,   /* float64 FMA on the vector ALU: reference arithmetic        */
+    ESN_F64 = 0,   /* float64, the reference's arithmetic: v_mfma_f64_16x16x4_f64 for batches (N_res <= 1024),
+                      float64 FMA on the vector ALU for a single sequence and larger reservoirs */
     ESN_F32 = 1,   /* v_mfma_f32_32x32x2_f32: exact float32 products + accumulate */
     ESN_F16 = 2,   /* v_mfma_f32_32x32x16_f16: fp16 operands, float32 accumulate  */
     ESN_BF16 = 3   /* v_mfma_f32_32x32x16_bf16: bf16 operands, float32 accumulate */
@@ -76,12 +77,13 @@ const char* esn_last_error(void);
 int esn_abi_version(void);
 
 /* Tuning / diagnostic knobs for benchmarks and A/B tests (no counterpart in the reference).  The
- * library reads ESN_SKEW, ESN_MFMA_GEOM, ESN_MFMA_GEOM_F32 and ESN_CHOL_SKIP from the environment
+ * library reads ESN_SKEW, ESN_MFMA_GEOM, ESN_MFMA_GEOM_F32, ESN_CHOL_SKIP and ESN_F64_MFMA from the environment
  * ONCE, at its first call, as initial values; afterwards only this call changes them:
  *   "skew"          "0" = in-step schedule for the fp16/bf16 predict kernel, else skewed (default)
  *   "mfma_geom"     "NW,MT,NT" re-cuts the fp16/bf16 predict tiling; ignored unless 32*NW*MT equals
  *   "mfma_geom_f32" the table's padded row count, so a packed image never goes stale; NULL = table
  *   "chol_skip"     bit mask of Cholesky-solve phases to drop (timing only, wrong results)
+ *   "f64_mfma"      "0" = ESN_F64 batches on the vector-ALU kernel instead of the float64 matrix pipe
  * Returns 0, or -1 for an unknown key. */
 int esn_debug_set(const char* key, const char* value);
 

@@ -42,18 +42,21 @@ def test_geometry_and_sizes(lib):
     assert lib.esn_tile_frames(F64, C.byref(sh)) == 8
     assert lib.esn_tile_frames(F32, C.byref(sh)) == 64
     assert lib.esn_tile_frames(F16, C.byref(sh)) == 128
-    # float64 image: K-major [n_res+n_in+n_out][n_res]
-    assert lib.esn_packed_weights_bytes(F64, C.byref(sh)) == 8 * (512 + 16 + 8) * 512
+    # float64 image: K-major [n_res+n_in+n_out][n_res] for the vector-ALU kernel, then the matrix-pipe
+    # kernel's fragment-ordered copy Mp x Kp, Kp = roundup(512+16+8, 8) = 536
+    assert lib.esn_packed_weights_bytes(F64, C.byref(sh)) == 8 * (512 + 16 + 8) * 512 + 8 * 512 * 536
     # MFMA images: Mp x Kp elements, Kp = roundup(512+16+8, 32) = 544
     assert lib.esn_packed_weights_bytes(F32, C.byref(sh)) == 4 * 512 * 544
     assert lib.esn_packed_weights_bytes(F16, C.byref(sh)) == 2 * 512 * 544
     assert lib.esn_packed_weights_bytes(BF16, C.byref(sh)) == 2 * 512 * 544
-    assert lib.esn_packed_readout_bytes(F64, C.byref(sh)) == 8 * 8 * 528
+    assert lib.esn_packed_readout_bytes(F64, C.byref(sh)) == 8 * 8 * 528 + 8 * 16 * 536
     assert lib.esn_packed_readout_bytes(F32, C.byref(sh)) == 16 * 544 * 4 + 16
     assert lib.esn_packed_readout_bytes(F16, C.byref(sh)) == 16 * 544 * 2 + 16   # hi rows 0-7, lo rows 8-15
     small = Shape(100, 2, 2, 1, 1)
     assert lib.esn_tile_frames(F32, C.byref(small)) == 64
     big = Shape(2048, 16, 8, 1, 1)
+    # N_res = 2048 in float64: vector-ALU kernel only (the float64 state of 16 frames does not fit LDS)
+    assert lib.esn_packed_weights_bytes(F64, C.byref(big)) == 8 * (2048 + 16 + 8) * 2048
     assert lib.esn_tile_frames(F16, C.byref(big)) == 32
     assert lib.esn_tile_frames(F32, C.byref(big)) < 0          # float32 state does not fit LDS
     assert b"unsupported" in lib.esn_last_error()
