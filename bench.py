@@ -311,7 +311,7 @@ def main():
             out = {k: rec[k] for k in keep}
             out.update(unit="OFDM symbols/s", **note)
             return out
-        for prec, g_sub in (("f32", G), ("f64", max(1, G // 8))):
+        for prec, g_sub in (("f32", G), ("f64", max(1, G // 4))):     # f64: 512 blocks = 1280 tiles of 32 frames = 5 per CU
             if prec == args.precision:
                 continue
             rec = run_config(torch, dist, params, precision=prec, fit_precision="auto", reservoirs="shared",
