@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("ESN_HIP_LIB") or os.path.join(_PKG, "libesn_hip.so") 
 F64, F32, F16, BF16 = 0, 1, 2, 3
 PRECISIONS = {"f64": F64, "f32": F32, "f16": F16, "bf16": BF16}
 NOISE_NONE, NOISE_TENSOR, NOISE_COUNTER = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Shape(C.Structure):
@@ -35,7 +35,8 @@ SIGNATURES = {
     "esn_pack_readout": (C.c_int, [C.c_int, C.POINTER(Shape), C.c_int, _dp, _vp, _vp]),
     "esn_predict_batch": (C.c_int, [C.c_int, C.POINTER(Shape), _vp, _vp, _dp, _dp, _dp, _dp, _dp,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
-                                    C.c_double, C.c_int, _dp, C.c_uint64, _dp, _vp]),
+                                    C.c_double, C.c_int, _dp, C.c_uint64, _dp, _vp, C.c_size_t, _vp]),
+    "esn_predict_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(Shape), C.c_int, C.c_int]),
     "esn_harvest_batch": (C.c_int, [C.c_int, C.POINTER(Shape), _vp, _dp, _dp, _dp, _dp, _dp, _dp,
                                     C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, _dp, _vp]),
     "esn_harvest_batch_f32": (C.c_int, [C.c_int, C.POINTER(Shape), _vp, _dp, _dp, _dp, _dp, _dp, _dp,

@@ -227,12 +227,20 @@ class ReservoirBank:
         with torch.cuda.device(self.device):
             if out is None:
                 out = torch.empty((b, T - transient, self.n_outputs), dtype=torch.float64, device=self.device)
+            # reservoirs beyond 1024 units run one GEMM launch per step out of a caller-owned workspace
+            wbytes = self.lib.esn_predict_workspace_bytes(PRECISIONS[precision], C.byref(self.shape), b,
+                                                          int(frames_per_group))
+            ws = None
+            if wbytes:
+                ws = getattr(self, "_workspace", None)
+                if ws is None or ws.numel() < wbytes:
+                    ws = self._workspace = torch.empty(wbytes, dtype=torch.uint8, device=self.device)
             check(self.lib.esn_predict_batch(
                 PRECISIONS[precision], C.byref(self.shape), ptr(self.packed_weights(precision)),
                 ptr(self.packed_readout(precision)), ptr(self.in_scale), ptr(self.in_shift),
                 ptr(self.t_scale), ptr(self.t_shift), ptr(U), b, int(frames_per_group), t_in, T,
                 int(transient), ptr(x0), ptr(y0), self.noise, nm, ptr(nz), int(seed) & (2**64 - 1),
-                ptr(out), _lib.stream_handle()), "esn_predict_batch")
+                ptr(out), ptr(ws), wbytes, _lib.stream_handle()), "esn_predict_batch")
         return out
 
     # ------------------------------------------------------------------ detector tail

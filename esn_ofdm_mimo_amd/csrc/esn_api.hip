@@ -15,12 +15,18 @@ size_t recur_f64_lds_bytes(int FB, int n_res, int n_in, int n_out);
 // esn_recur_f64_mfma.hip
 bool f64_mfma_geometry(int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_f64_mfma(const RecurParams& p, hipStream_t stream);
+// esn_recur_big.hip
+bool big_path_applies(int precision, const RecurParams& p);
+int big_slots(const RecurParams& p);
+size_t big_workspace_bytes(int n_slots, int Mp, int Kp);
+int launch_recur_big(int precision, const RecurParams& p, size_t wo_big_off, void* workspace, hipStream_t stream);
 // esn_recur_mfma.hip
 bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
 // esn_pack.hip
 size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
 size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
+size_t wout_big_offset(int precision, int n_out, const Geometry& g);
 size_t f64_w_offset(int n_res, int n_in, int n_out);
 size_t f64_wout_offset(int n_res, int n_in, int n_out);
 int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g, const double* W,
@@ -71,6 +77,8 @@ Knobs& knobs() {
         x.chol_skip = v ? atoi(v) : 0;
         v = getenv("ESN_F64_MFMA");
         x.f64_mfma = (v && v[0] == '0') ? 0 : 1;
+        v = getenv("ESN_BIG_GEMM");
+        x.big_gemm = (v && v[0] == '0') ? 0 : 1;
         return x;
     }();
     return k;
@@ -127,7 +135,7 @@ extern "C" {
 
 const char* esn_last_error(void) { return g_err; }
 
-int esn_abi_version(void) { return 5; }
+int esn_abi_version(void) { return 6; }
 
 int esn_debug_set(const char* key, const char* value) {
     if (!key) return fail(-1, "esn_debug_set: null key");
@@ -137,6 +145,7 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "mfma_geom_f32")) { parse3(value, k.geom32); return 0; }
     if (!strcmp(key, "chol_skip")) { k.chol_skip = value ? atoi(value) : 0; return 0; }
     if (!strcmp(key, "f64_mfma")) { k.f64_mfma = (value && value[0] == '0') ? 0 : 1; return 0; }
+    if (!strcmp(key, "big_gemm")) { k.big_gemm = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }
 
@@ -229,7 +238,8 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
                       const double* in_scale, const double* in_shift, const double* t_scale,
                       const double* t_shift, const double* U, int n_frames, int frames_per_group, int T_in,
                       int T, int transient, const double* x0, const double* y0, double noise, int noise_mode,
-                      const double* noise_u, uint64_t seed, double* Y, void* stream) {
+                      const double* noise_u, uint64_t seed, double* Y, void* workspace, size_t workspace_bytes,
+                      void* stream) {
     RecurParams p;
     int rc = fill_common(p, precision, shape, "esn_predict_batch");
     if (rc) return rc;
@@ -257,10 +267,30 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
     p.Y = Y;
     ESN_SET_STAMPS(p);
+    // large reservoirs: one GEMM launch per step when the caller lends a workspace (else the persistent kernel)
+    if (workspace && knobs().big_gemm && p.g.big && big_path_applies(precision, p)) {
+        const size_t need = big_workspace_bytes(big_slots(p), p.g.Mp, p.g.Kp);
+        if (workspace_bytes < need)
+            return fail(-1, "esn_predict_batch: workspace holds %zu bytes, esn_predict_workspace_bytes says %zu",
+                        workspace_bytes, need);
+        p.Fpad = round_up(p.F, 16);
+        return hip_fail(launch_recur_big(precision, p, wout_big_offset(precision, p.n_out, p.g), workspace,
+                                         (hipStream_t)stream), "esn_predict_batch");
+    }
     int e = m64 ? launch_recur_f64_mfma(p, (hipStream_t)stream)
             : (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
                                      : launch_recur_mfma(precision, p, (hipStream_t)stream);
     return hip_fail(e, "esn_predict_batch");
+}
+
+size_t esn_predict_workspace_bytes(int precision, const esn_shape_t* shape, int n_frames, int frames_per_group) {
+    RecurParams p;
+    if (n_frames <= 0 || frames_per_group <= 0) return 0;
+    if (fill_common(p, precision, shape, "esn_predict_workspace_bytes")) return 0;
+    p.harvest = 0; p.F = frames_per_group;
+    p.n_groups = (n_frames + frames_per_group - 1) / frames_per_group;
+    if (!p.g.big || !big_path_applies(precision, p)) return 0;
+    return big_workspace_bytes(big_slots(p), p.g.Mp, p.g.Kp);
 }
 
 static int harvest_common(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,

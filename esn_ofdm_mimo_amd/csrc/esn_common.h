@@ -22,6 +22,8 @@ struct Geometry {
     int ro_parts;    // readout images per group: 1, or 2 (hi + lo) for fp16/bf16 with n_out > 8
     int ro_fold;     // fp16/bf16, n_out <= 8: rows 0-7 = hi, rows 8-15 = lo of ONE 16-row image
     int skew;        // predict: the two waves of a SIMD run one third of a step apart (esn_recur_mfma_impl.h)
+    int big;         // fp16/bf16, N_res > 1024: the launch-per-step GEMM path (esn_recur_big.hip) serves this shape;
+                     // the packed read-out then carries that path's image behind the persistent kernel's
     int m64;         // ESN_F64: 1 = the float64 matrix-pipe kernel (esn_recur_f64_mfma.hip) fits this shape;
     int Bt64;        //          then Mp..Ks, MT, NT describe ITS tiling, Bt64 its frames per tile and Bt
                      //          stays the tile of the vector-ALU kernel (esn_recur_f64.hip)
@@ -157,6 +159,7 @@ struct Knobs {
     int geom32[3];         // float32 predict tiling override
     int chol_skip;         // bit mask of Cholesky-solve phases to drop (tools/time_chol.py)
     int f64_mfma;          // 1 (default): float64 batches run on the matrix pipe; 0: vector-ALU kernel (A/B tests)
+    int big_gemm;          // 1 (default): N_res > 1024 predict runs as one GEMM launch per step when a workspace is given
 };
 Knobs& knobs();
 

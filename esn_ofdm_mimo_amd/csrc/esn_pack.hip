@@ -109,6 +109,13 @@ __global__ void pack_w_mfma_kernel(const double* W, const double* Win, const dou
     }
 }
 
+// bytes of the persistent kernels' read-out image (the big path's image, when present, follows 16-byte aligned)
+__host__ __device__ inline size_t packed_wout_persistent_bytes(int es, int n_out, const Geometry& g) {
+    const int n_ot = (n_out + 15) / 16;
+    return (size_t)g.ro_parts * n_ot * 16 * g.Kp * es + 16;
+}
+size_t big_wout_image_bytes(int Mp);
+
 // Readout image for the 16x16 MFMA: [part][ot][64-byte k-group][lane][16 B] then a
 // 16-byte trailer {1/gain, gain, 0, 0} (float).  gain is a power of two that brings
 // max|W_out| of the group to ~2^10 so fp16 images keep full precision; part 1 holds
@@ -168,6 +175,30 @@ __global__ __launch_bounds__(256) void pack_wout_mfma_kernel(const double* Wout,
         float* tr = reinterpret_cast<float*>(out + g.ro_parts * per_part * ES);
         tr[0] = (float)(1.0 / gain); tr[1] = (float)gain; tr[2] = 0.f; tr[3] = 0.f;
     }
+    if (ES == 2 && g.big) {
+        // image of the launch-per-step GEMM path (esn_recur_big.hip): A operand of a 32x32x16 MFMA whose B
+        // operand is an accumulator tile -- [row tile of 32 k][k-step s2][lane (o = lane & 31, h)][8 elements],
+        // element e <-> k = 32 rt + 16 s2 + 8 (e >> 2) + 4 h + (e & 3); rows 0-7 hi, 8-15 rounding residual
+        char* big = out + (packed_wout_persistent_bytes(ES, n_out, g) + 15) / 16 * 16;
+        T* bimg = reinterpret_cast<T*>(big);
+        const size_t nb = (size_t)g.Mp * 32;
+        for (size_t i = threadIdx.x; i < nb; i += blockDim.x) {
+            const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), s2 = (int)((i >> 9) & 1), rt = (int)(i >> 10);
+            const int o = lane & 31, hA = lane >> 5;
+            const int k = 32 * rt + 16 * s2 + 8 * (e >> 2) + 4 * hA + (e & 3);
+            const int oo = o & 7;
+            double v = (o < 16 && oo < n_out && k < n_res) ? wo[(size_t)oo * ncols + k] * gain : 0.0;
+            const T hi = (T)(float)v;
+            const T lo = (T)(float)(v - (double)(float)hi);
+            bimg[i] = o < 8 ? hi : lo;
+        }
+        float* wu = reinterpret_cast<float*>(big + (size_t)g.Mp * 64);
+        for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+            const int o = i >> 4, ii = i & 15;
+            wu[i] = (o < n_out && ii < n_in) ? (float)(wo[(size_t)o * ncols + n_res + ii] * gain) : 0.f;
+        }
+        if (threadIdx.x == 0) { wu[128] = (float)(1.0 / gain); wu[129] = (float)gain; wu[130] = 0.f; wu[131] = 0.f; }
+    }
 }
 
 // ESN_F64 images hold the vector-ALU kernel's copy first and, when the matrix-pipe kernel fits the
@@ -190,8 +221,11 @@ size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Ge
     if (precision == ESN_F64)
         return f64_wout_offset(n_res, n_in, n_out) + (g.m64 ? sizeof(double) * (size_t)16 * g.Kp : 0);
     const int es = (precision == ESN_F32) ? 4 : 2;
-    const int n_ot = (n_out + 15) / 16;
-    return (size_t)g.ro_parts * n_ot * 16 * g.Kp * es + 16;
+    const size_t base = packed_wout_persistent_bytes(es, n_out, g);
+    return g.big ? (base + 15) / 16 * 16 + big_wout_image_bytes(g.Mp) : base;
+}
+size_t wout_big_offset(int precision, int n_out, const Geometry& g) {
+    return (packed_wout_persistent_bytes(precision == ESN_F32 ? 4 : 2, n_out, g) + 15) / 16 * 16;
 }
 
 int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g, const double* W,

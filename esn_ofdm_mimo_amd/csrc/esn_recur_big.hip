@@ -1,0 +1,424 @@
+// Large reservoirs (N_res > 1024, BASELINE configs[4]: 2048): the recurrence as ONE GEMM LAUNCH PER
+// TIMESTEP.  The persistent kernels keep the state of a frame tile in LDS and stream the weights; at
+// N_res = 2048 the fp16 weight image is 8.5 MB -- beyond one XCD's L2 -- and 160 KB of LDS hold the
+// state of only 32 frames, so every CU re-streamed 8.5 MB from the Infinity Cache per step for 32
+// frames (6 % of the MFMA peak, round 1).  Here the state lives in HBM / Infinity Cache in MFMA
+// fragment order and step s is a tiled GEMM with a fused epilogue:
+//
+//   X_{s+1}[Mp x F] = act( Wext[Mp x Kp] * [X_s ; U_s ; F_s] )          256 x 256 tile per workgroup
+//
+//   * both operands arrive by LDS-DMA in 1 KB fragments (the weight image of esn_pack_weights and
+//     the state image are already in the order a wave's ds_read_b128 consumes them: no swizzle, no
+//     conflicts), double-buffered 64-deep k-chunks, counted vmcnt + raw s_barrier;
+//   * 8 waves = 2 (rows) x 4 (frames), 4 x 2 accumulator tiles of 32 x 32 each;
+//   * a small "prep" launch ahead of every GEMM launch turns the previous launch's read-out partials
+//     into Y_s (output row s-1 -> HBM, unscaled) and writes the [U_s ; F_s] k-groups of the state
+//     image (scaled inputs, fed-back output), so the GEMM sees ONE uniform operand: Kp/64 chunks;
+//   * epilogue: tanh + state noise -> fp16 -> next state image (coalesced 8-byte pieces), and the
+//     read-out partial Wout[:, these 256 rows] x_{s+1} with the accumulator tile used directly as the
+//     B operand of a 32x32x16 MFMA (guide: "an accumulator tile as the next MFMA's operand");
+//   * workgroup -> tile map: the Mp/256 row tiles of one frame tile run side by side on one XCD (they
+//     share the state fragments through that XCD's L2), frame tiles are dealt over the 8 XCDs.
+//
+// The launch boundaries are the per-step dependencies (X_{s+1} needs every row of X_s, Y_s every row
+// tile's partial): two boundaries of ~1.5 us per step against ~0.3-0.5 ms of GEMM at the benchmark size.  Arithmetic and noise stream are those of the
+// persistent fp16/bf16 kernels (same packed weights incl. the 2 log2 e pre-scale, same counter noise).
+#include "esn_recur_mfma_impl.h"
+
+namespace esn {
+
+struct BigParams {
+    RecurParams r;
+    int n_slots;          // padded slot axis, multiple of 256
+    int n_mt;             // row tiles of 256: Mp / 256
+    int nkgS, nkg;        // 32-byte k-groups: state (Mp/16) and total (Kp/16, a multiple of 4)
+    int step;
+    const char* x_in;     // state image of step s   [n_slots/32][nkg][64 lanes][16 B]: state groups, then [U;F], zeros
+    char* x_out;          // ... of step s+1
+    const float* yp_in;   // [n_mt][n_slots][8] read-out partials (x gain) of X_s, written by the previous GEMM launch
+    float* yp_out;
+    size_t wo_big_off;    // byte offset of the big-path read-out image inside a group's packed read-out
+};
+
+template <typename E>
+__device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+    typedef E vec4 __attribute__((ext_vector_type(4)));
+    const vec4 v = {(E)a, (E)b, (E)c, (E)d};
+    return __builtin_bit_cast(u32x2, v);
+}
+
+constexpr int BIG_STAGE = 65536;                      // one k-chunk: A 32 KB + B 32 KB
+constexpr int BIG_LDS = 2 * BIG_STAGE;                // (the epilogue's 8 KB scratch aliases stage 0)
+
+size_t big_workspace_bytes(int n_slots, int Mp, int Kp) {
+    return 2 * ((size_t)n_slots * Kp * 2) + 2 * ((size_t)(Mp / 256) * n_slots * 8 * 4);
+}
+// per-group read-out image of this path: [Mp/32 row tiles][2 k-steps][64 lanes][16 B] (rows 0-7 hi, 8-15 lo
+// of W_out gain, k in accumulator order), then (W_out gain)[:, inputs] as float [8][16], then {1/gain, gain, 0, 0}
+size_t big_wout_image_bytes(int Mp) { return (size_t)Mp * 64 + 512 + 16; }
+
+// both state images: X_0 = x0 of the frame's group (or zeros) in the first, zeros in the second; the
+// [U;F] and padding k-groups zero in both (prep writes [U;F] every step, the padding groups stay zero)
+template <typename TR>
+__global__ void big_init_kernel(BigParams bp, char* x0_img, char* x1_img) {
+    const RecurParams& p = bp.r;
+    const size_t n = (size_t)(bp.n_slots / 32) * bp.nkg * 64;        // 16-byte pieces: [ct][kg][lane]
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const size_t j = i >> 6;
+        const int kg = (int)(j % bp.nkg);
+        const int ct = (int)(j / bp.nkg);
+        const int slot = ct * 32 + (lane & 31);
+        int grp;
+        const int fr = slot_frame(p, slot, grp);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kg * 16 + 8 * (lane >> 5) + e;
+            v[e] = (fr >= 0 && p.x0 && k < p.n_res) ? (float)p.x0[(size_t)grp * p.n_res + k] : 0.f;
+        }
+        *reinterpret_cast<u32x2*>(x0_img + i * 16) = pack4<typename TR::elem>(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<u32x2*>(x0_img + i * 16 + 8) = pack4<typename TR::elem>(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<u32x4*>(x1_img + i * 16) = u32x4{0, 0, 0, 0};
+    }
+}
+
+// prep(s), one thread per slot, ahead of GEMM launch s (and once more after the last one):
+//   s >= 1:  Y_s = (1/gain) sum_m partials(X_s) + W_out[:, inputs] U_{s-1}    -> output row s-1 (unscaled)
+//   s == 0:  Y_0 = y0 of the group (continuation) or 0
+//   s <  S:  [U_s ; F_s = Y_s] -> k-groups nkgS, nkgS+1 of the image GEMM launch s reads (bp.x_out here)
+// U_{s-1} is read back from the image of the previous step (bp.x_in), in the operand type -- the same
+// rounded inputs the persistent kernels multiply with W_out.
+template <typename TR>
+__global__ __launch_bounds__(256) void big_prep_kernel(BigParams bp) {
+    __shared__ float wou[17 * 128];                       // (W_out gain)[:, inputs] of the block's groups
+    __shared__ float inv_gain[17];
+    const RecurParams& p = bp.r;
+    const int n_in = p.n_in, n_out = p.n_out;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int grp_first = (blockIdx.x * 256) / p.Fpad;
+    for (int i = threadIdx.x; i < 17 * 128; i += 256) {
+        const int g = grp_first + (i >> 7);
+        const char* gimg = reinterpret_cast<const char*>(p.packed_wout) + (size_t)(g < p.n_groups ? g : 0) * p.wout_stride + bp.wo_big_off;
+        wou[i] = *reinterpret_cast<const float*>(gimg + (size_t)p.g.Mp * 64 + (size_t)(i & 127) * 4);
+        if ((i & 127) == 0) inv_gain[i >> 7] = *reinterpret_cast<const float*>(gimg + (size_t)p.g.Mp * 64 + 512);
+    }
+    __syncthreads();
+    int grp;
+    const int fr = slot_frame(p, slot, grp);
+    const bool live = fr >= 0;
+    const size_t fr_c = live ? (size_t)fr : 0, grp_c = live ? (size_t)grp : 0;
+    const int gi = live ? grp - grp_first : 0;
+    const int s = bp.step;
+    const int ct = slot >> 5, lr = slot & 31;
+    const int kin_p = p.g.kfb - p.g.kin;
+    // every load is unconditional (clamped indices, masked results): no branch, one wait
+    float part[8][8];
+#pragma unroll
+    for (int mm = 0; mm < 8; ++mm) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(bp.yp_in + ((size_t)(mm < bp.n_mt ? mm : 0) * bp.n_slots + slot) * 8);
+        const f32x4 a = src[0], b = src[1];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { part[mm][o] = a[o]; part[mm][4 + o] = b[o]; }
+    }
+    float uprev[16];                                       // k - kin = 0..15 of the previous step's [U;F] group
+    {
+        const char* g0 = bp.x_in + ((size_t)ct * bp.nkg + bp.nkgS) * 1024;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            float t4[4];
+            TR::load4(g0 + (size_t)(lr + 32 * (c4 >> 1)) * 16 + 8 * (c4 & 1), t4);
+            uprev[4 * c4] = t4[0]; uprev[4 * c4 + 1] = t4[1]; uprev[4 * c4 + 2] = t4[2]; uprev[4 * c4 + 3] = t4[3];
+        }
+    }
+    const int row = s + p.in_row_off;
+    const int row_c = row < p.T_in ? row : 0;
+    const bool has_isc = p.in_scale != nullptr, has_ish = p.in_shift != nullptr, has_y0 = p.y0 != nullptr,
+               has_tsc = p.t_scale != nullptr, has_tsh = p.t_shift != nullptr;
+    const double* sc_in = p.in_scale ? p.in_scale : p.U;       // (any valid address; the value is masked below)
+    const double* sh_in = p.in_shift ? p.in_shift : p.U;
+    float uu[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ic = i < n_in ? i : 0;
+        const double raw = p.U[(fr_c * p.T_in + row_c) * n_in + ic];
+        const float scv = (float)sc_in[grp_c * n_in + ic], shv = (float)sh_in[grp_c * n_in + ic];   // loaded, then masked
+        const float sc = has_isc ? scv : 1.f, sh = has_ish ? shv : 0.f;
+        const float v = fmaf(row < p.T_in ? (float)raw : 0.f, sc, sh);       // rows past T_in: zeros BEFORE scaling
+        uu[i] = (live && i < n_in) ? v : 0.f;
+    }
+    const double* y0p = p.y0 ? p.y0 : p.U;
+    const double* tsc = p.t_scale ? p.t_scale : p.U;
+    const double* tsh = p.t_shift ? p.t_shift : p.U;
+    const int orow = s - 1 - p.transient;
+    const int out_rows = p.S - p.transient;
+    float yy[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int oc = o < n_out ? o : 0;
+        const float y0l = (float)y0p[grp_c * n_out + oc];
+        const double tscl = tsc[grp_c * n_out + oc], tshl = tsh[grp_c * n_out + oc];
+        const float y0v = has_y0 ? y0l : 0.f;
+        float y = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < 8; ++mm) y += (mm < bp.n_mt) ? part[mm][o] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y = fmaf(wou[gi * 128 + o * 16 + i], uprev[i], y);
+        y *= inv_gain[gi];
+        y = (s == 0) ? y0v : y;
+        const double sc = has_tsc ? tscl : 1.0;
+        const double sh = has_tsh ? tshl : 0.0;
+        if (live && o < n_out && s > 0 && orow >= 0)
+            p.Y[((size_t)fr * out_rows + orow) * n_out + o] = ((double)y - sh) / sc;
+        yy[o] = (live && o < n_out) ? y : 0.f;
+    }
+    if (s < p.S) {
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                float e8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = 16 * g2 + 8 * hh + e;              // k - kin
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v = (kk == i) ? uu[i] : v;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) v = (kk == kin_p + o) ? yy[o] : v;
+                    e8[e] = v;
+                }
+                char* d = bp.x_out + ((size_t)ct * bp.nkg + bp.nkgS + g2) * 1024 + (size_t)(lr + 32 * hh) * 16;
+                *reinterpret_cast<u32x2*>(d) = pack4<typename TR::elem>(e8[0], e8[1], e8[2], e8[3]);
+                *reinterpret_cast<u32x2*>(d + 8) = pack4<typename TR::elem>(e8[4], e8[5], e8[6], e8[7]);
+            }
+    }
+}
+
+template <typename TR, int NOISE>
+__global__ __launch_bounds__(512) void big_step_kernel(BigParams bp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RecurParams& p = bp.r;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;             // 2 x 4 waves: rows 128 wm.., frames 64 wn..
+    const int r = lane & 31, h = lane >> 5;
+    const int n_res = p.n_res;
+    const int nkg = bp.nkg;
+
+    // workgroup -> (row tile m, frame tile n): the n_mt row tiles of a frame tile are consecutive ids on one XCD
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int m = local % bp.n_mt;
+    const int n = (local / bp.n_mt) * 8 + xcd;
+    const int slot0 = n * 256;
+    if (slot0 >= bp.n_slots) return;
+
+    char* stage = smem;                                               // [2][A 32 KB | B 32 KB]
+    float* red = reinterpret_cast<float*>(stage);                     // epilogue: [256 frames][8] (aliases stage 0)
+
+    // ---- main loop: Kp/64 chunks of four k-groups, LDS-DMA double-buffered ---------------------------
+    const int lane16 = lane * 16;
+    const size_t x_bytes = (size_t)bp.n_slots * p.g.Kp * 2;
+    // wave w < 4 fetches row tiles 2w, 2w+1 of A; wave w >= 4 column tiles 2(w-4), 2(w-4)+1 of B: 8 pieces each
+    const bool is_a = wave < 4;
+    const int pair = (wave & 3) * 2;
+    const int src_t0 = (is_a ? (m * 8 + pair) : ((slot0 >> 5) + pair)) * nkg;
+    const int dst_off = (is_a ? 0 : 32768) + pair * 4096;
+    // one descriptor per wave, built from values the compiler can PROVE wave-uniform (readfirstlane of the
+    // pointer halves and the size): otherwise every DMA is wrapped in a waterfall loop (guide T20)
+    const uint64_t dma_ptr = is_a ? (uint64_t)reinterpret_cast<uintptr_t>(p.packed_w) : (uint64_t)reinterpret_cast<uintptr_t>(bp.x_in);
+    const uint32_t dma_lo = __builtin_amdgcn_readfirstlane((uint32_t)dma_ptr);
+    const uint32_t dma_hi = __builtin_amdgcn_readfirstlane((uint32_t)(dma_ptr >> 32));
+    const int dma_size = __builtin_amdgcn_readfirstlane(is_a ? (int)p.wset_stride : (int)x_bytes);
+    const __amdgpu_buffer_rsrc_t dma_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>((uintptr_t)(((uint64_t)dma_hi << 32) | dma_lo)), 0, dma_size, 0x00020000);
+    auto issue = [&](int c, int buf) {
+        char* dst = stage + (size_t)buf * BIG_STAGE + dst_off;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rsrc, (__attribute__((address_space(3))) void*)(dst + (t * 4 + kg) * 1024),
+                                                         16, lane16, (src_t0 + t * nkg + 4 * c + kg) * 1024, 0, 0);
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+    auto compute = [&](int buf) {
+        const char* ab = stage + (size_t)buf * BIG_STAGE + (size_t)(wm * 4) * 4096 + lane16;
+        const char* bb = stage + (size_t)buf * BIG_STAGE + 32768 + (size_t)(wn * 2) * 4096 + lane16;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            u32x4 a[4], b[2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const u32x4*>(ab + mt * 4096 + kg * 1024);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const u32x4*>(bb + nt * 4096 + kg * 1024);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) TR::mma32(acc[mt][nt], a[mt], b[nt]);
+        }
+    };
+    const int nch = nkg / 4;
+    issue(0, 0);
+    for (int c = 0; c + 1 < nch; ++c) {
+        issue(c + 1, (c + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's pieces of chunk c have landed
+        __builtin_amdgcn_s_barrier();                          // ... and everybody else's
+        compute(c & 1);
+        __builtin_amdgcn_s_barrier();                          // chunk c read: its buffer may be refilled
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute((nch - 1) & 1);
+    __syncthreads();                                           // stage buffers free (the epilogue's scratch aliases them)
+
+    // ---- epilogue: activation + noise -> next state image; read-out partial ---------------------------
+    const float noise = (float)p.noise;
+    const float n_c1 = noise * (1.0f / 256.0f), n_c0 = noise * (0.5f / 256.0f - 0.5f);
+    const char* wo_base = reinterpret_cast<const char*>(p.packed_wout) + bp.wo_big_off;
+    const __amdgpu_buffer_rsrc_t xo_rsrc = __builtin_amdgcn_make_buffer_rsrc(bp.x_out, 0, (int)x_bytes, 0x00020000);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int fcol = wn * 64 + nt * 32 + r;
+        int fgrp;
+        const int fr = slot_frame(p, slot0 + fcol, fgrp);
+        const int ct_g = (slot0 >> 5) + wn * 2 + nt;
+        // the column tile's two 16-frame halves may belong to different groups (different W_out)
+        const int g_lo = (ct_g * 32) / p.Fpad, g_hi = (ct_g * 32 + 16) / p.Fpad;       // wave-uniform
+        uint32_t key = 0;
+        const double* nz = nullptr;
+        if (NOISE == ESN_NOISE_COUNTER) key = noise_key(p.seed, (uint32_t)fr, (uint32_t)bp.step);
+        if (NOISE == ESN_NOISE_TENSOR && fr >= 0) nz = p.noise_u + ((size_t)fr * p.S + bp.step) * n_res;
+        f32x16 racc_lo, racc_hi;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { racc_lo[i] = 0.f; racc_hi[i] = 0.f; }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int rt_g = m * 8 + wm * 4 + mt;
+            // W_out fragments of this row tile (two k-steps), issued ahead of the activation arithmetic
+            u32x4 wa_lo[2], wa_hi[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                wa_lo[s2] = *reinterpret_cast<const u32x4*>(wo_base + (size_t)(g_lo < p.n_groups ? g_lo : 0) * p.wout_stride
+                                                            + (size_t)(rt_g * 2 + s2) * 1024 + lane16);
+                wa_hi[s2] = *reinterpret_cast<const u32x4*>(wo_base + (size_t)(g_hi < p.n_groups ? g_hi : 0) * p.wout_stride
+                                                            + (size_t)(rt_g * 2 + s2) * 1024 + lane16);
+            }
+            u32x2 xh[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rt_g * 32 + 8 * q + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[mt][nt][4 * q + j]);
+                if (NOISE == ESN_NOISE_COUNTER) {
+                    const uint32_t sq = noise_quad(key, (uint32_t)(row >> 2));
+                    v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
+                    v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
+                    v[2] = fmaf((float)((sq >> 16) & 0xffU), n_c1, v[2] + n_c0);
+                    v[3] = fmaf((float)(sq >> 24), n_c1, v[3] + n_c0);
+                } else if (NOISE == ESN_NOISE_TENSOR) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+                }
+                xh[q] = pack4<typename TR::elem>(v[0], v[1], v[2], v[3]);
+                // state image: k-group 2 rt + (q >> 1), lane r + 32 (q & 1), bytes 8 h .. 8 h + 7
+                const int soff = ((ct_g * nkg + 2 * rt_g + (q >> 1)) * 64 + 32 * (q & 1)) * 16;
+                __builtin_amdgcn_raw_buffer_store_b64(xh[q], xo_rsrc, r * 16 + 8 * h, soff, 0);
+            }
+            // read-out partial: the converted tile is the B operand (rows of X = k), k-step s2 = registers 8 s2 .. 8 s2 + 7
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 xb = {xh[2 * s2][0], xh[2 * s2][1], xh[2 * s2 + 1][0], xh[2 * s2 + 1][1]};
+                TR::mma32(racc_lo, wa_lo[s2], xb);
+                TR::mma32(racc_hi, wa_hi[s2], xb);
+            }
+        }
+        // rows 0-7 of the image hold hi(W_out gain), rows 8-15 the rounding residual: lane (r, h) sums
+        // registers j and 4 + j into output o = 4 h + j of its frame
+        float y4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y4[j] = (r >= 16) ? racc_hi[j] + racc_hi[4 + j] : racc_lo[j] + racc_lo[4 + j];
+        // sum over the two row halves of the workgroup (wm = 1 -> LDS -> wm = 0), then one 16-byte store
+        if (wm == 1) *reinterpret_cast<f32x4*>(red + (size_t)fcol * 8 + 4 * h) = f32x4{y4[0], y4[1], y4[2], y4[3]};
+        __syncthreads();
+        if (wm == 0) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(red + (size_t)fcol * 8 + 4 * h);
+            *reinterpret_cast<f32x4*>(bp.yp_out + ((size_t)m * bp.n_slots + slot0 + fcol) * 8 + 4 * h) =
+                f32x4{y4[0] + o[0], y4[1] + o[1], y4[2] + o[2], y4[3] + o[3]};
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TR>
+static int launch_big_t(const RecurParams& rp, size_t wo_big_off, void* workspace, hipStream_t stream) {
+    BigParams bp;
+    bp.r = rp;
+    const int Mp = rp.g.Mp, Kp = rp.g.Kp;
+    bp.n_slots = round_up(rp.n_groups * rp.Fpad, 256);
+    bp.n_mt = Mp / 256;
+    bp.nkgS = Mp / 16;
+    bp.nkg = Kp / 16;
+    bp.wo_big_off = wo_big_off;
+    char* ws = reinterpret_cast<char*>(workspace);
+    const size_t xb = (size_t)bp.n_slots * Kp * 2, yb = (size_t)bp.n_mt * bp.n_slots * 8 * 4;
+    char* X[2] = {ws, ws + xb};
+    float* YP[2] = {reinterpret_cast<float*>(ws + 2 * xb), reinterpret_cast<float*>(ws + 2 * xb + yb)};
+    bp.step = 0; bp.x_in = X[1]; bp.x_out = X[0]; bp.yp_in = YP[0]; bp.yp_out = YP[1];
+    hipLaunchKernelGGL(big_init_kernel<TR>, dim3(2048), dim3(256), 0, stream, bp, X[0], X[1]);
+    hipError_t e = hipMemsetAsync(YP[0], 0, yb, stream);          // prep(0) reads (and discards) partials
+    if (e != hipSuccess) return (int)e;
+    const int n_nt8 = (bp.n_slots / 256 + 7) / 8;
+    const dim3 grid(8 * n_nt8 * bp.n_mt);
+    const void* k_none = reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_NONE>);
+    const void* k_tens = reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_TENSOR>);
+    const void* k_cnt = reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_COUNTER>);
+    e = hipFuncSetAttribute(rp.noise_mode == ESN_NOISE_NONE ? k_none : rp.noise_mode == ESN_NOISE_TENSOR ? k_tens : k_cnt,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+    if (e != hipSuccess) return (int)e;
+    for (int s = 0; s <= rp.S; ++s) {
+        // prep(s): partials of X_s (from GEMM s-1, in YP[s & 1]) -> Y row s-1; [U_s ; F_s] -> image X[s & 1]
+        bp.step = s;
+        bp.x_in = X[(s + 1) & 1];          // previous step's image: its [U;F] group holds U_{s-1}
+        bp.x_out = X[s & 1];
+        bp.yp_in = YP[s & 1];
+        hipLaunchKernelGGL(big_prep_kernel<TR>, dim3(bp.n_slots / 256), dim3(256), 0, stream, bp);
+        if (s == rp.S) break;
+        bp.x_in = X[s & 1]; bp.x_out = X[(s + 1) & 1];
+        bp.yp_out = YP[(s + 1) & 1];
+        switch (rp.noise_mode) {
+            case ESN_NOISE_NONE:
+                hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_NONE>), grid, dim3(512), BIG_LDS, stream, bp); break;
+            case ESN_NOISE_TENSOR:
+                hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_TENSOR>), grid, dim3(512), BIG_LDS, stream, bp); break;
+            default:
+                hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_COUNTER>), grid, dim3(512), BIG_LDS, stream, bp); break;
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+// shapes this path serves: fp16/bf16 predict, shared reservoir, n_in <= 16, n_out <= 8, Mp a multiple of 256
+bool big_path_applies(int precision, const RecurParams& p) {
+    return (precision == ESN_F16 || precision == ESN_BF16) && !p.harvest && p.n_wsets == 1 && p.n_res > 1024 &&
+           p.n_in <= 16 && p.n_out <= 8 && p.g.Mp % 256 == 0 && p.g.Mp <= 2048 && p.g.Kp % 64 == 0 &&
+           p.g.Kp - p.g.Mp >= 32 && p.g.kfb - p.g.kin + round_up(p.n_out, 4) <= 32 &&
+           (size_t)round_up(p.n_groups * round_up(p.F, 16), 256) * p.g.Kp * 2 < 0x7fffffffu;
+}
+int big_slots(const RecurParams& p) { return round_up(p.n_groups * round_up(p.F, 16), 256); }
+
+int launch_recur_big(int precision, const RecurParams& p, size_t wo_big_off, void* workspace, hipStream_t stream) {
+    if (precision == ESN_F16) return launch_big_t<TraitsF16>(p, wo_big_off, workspace, stream);
+    if (precision == ESN_BF16) return launch_big_t<TraitsBF16>(p, wo_big_off, workspace, stream);
+    return -1;
+}
+
+}  // namespace esn

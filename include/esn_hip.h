@@ -84,6 +84,7 @@ int esn_abi_version(void);
  *   "mfma_geom_f32" the table's padded row count, so a packed image never goes stale; NULL = table
  *   "chol_skip"     bit mask of Cholesky-solve phases to drop (timing only, wrong results)
  *   "f64_mfma"      "0" = ESN_F64 batches on the vector-ALU kernel instead of the float64 matrix pipe
+ *   "big_gemm"      "0" = N_res > 1024 predict on the persistent kernel even when a workspace is given
  * Returns 0, or -1 for an unknown key. */
 int esn_debug_set(const char* key, const char* value);
 
@@ -124,7 +125,12 @@ int esn_pack_readout(int precision, const esn_shape_t* shape, int n_groups,
  *                 output (continuation=True: laststate/lastoutput, :234-237) or NULL (zeros)
  *   noise_u       [B][T][n_res] uniforms when noise_mode == ESN_NOISE_TENSOR
  *   Y             [B][T-transient][n_out], unscaled (:255)
+ *   workspace     device scratch of esn_predict_workspace_bytes(...) bytes, or NULL.  Only reservoirs
+ *                 beyond 1024 units in fp16/bf16 use it (there the recurrence runs as one tiled GEMM launch
+ *                 per timestep with the state images in the workspace); with NULL every shape runs on the
+ *                 persistent kernels.  No allocation happens inside the call either way.
  */
+size_t esn_predict_workspace_bytes(int precision, const esn_shape_t* shape, int n_frames, int frames_per_group);
 int esn_predict_batch(int precision, const esn_shape_t* shape,
                       const void* packed_w, const void* packed_wout,
                       const double* in_scale, const double* in_shift,
@@ -133,7 +139,7 @@ int esn_predict_batch(int precision, const esn_shape_t* shape,
                       int T_in, int T, int transient,
                       const double* x0, const double* y0,
                       double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, double* Y, void* stream);
+                      uint64_t seed, double* Y, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Batched state harvest of ESN.fit: one training sequence per group.
  *

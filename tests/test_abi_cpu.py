@@ -60,6 +60,12 @@ def test_geometry_and_sizes(lib):
     assert lib.esn_tile_frames(F16, C.byref(big)) == 32
     assert lib.esn_tile_frames(F32, C.byref(big)) < 0          # float32 state does not fit LDS
     assert b"unsupported" in lib.esn_last_error()
+    # fp16, N_res = 2048: K padded to whole 64-deep chunks (2112); the packed read-out carries the image of the
+    # launch-per-step GEMM path behind the persistent kernel's; its workspace = 2 state images + 2 partial buffers
+    assert lib.esn_packed_weights_bytes(F16, C.byref(big)) == 2 * 2048 * 2112
+    assert lib.esn_packed_readout_bytes(F16, C.byref(big)) == (16 * 2112 * 2 + 16) + (2048 * 64 + 512 + 16)
+    assert lib.esn_predict_workspace_bytes(F16, C.byref(big), 150, 75) == 2 * 256 * 2112 * 2 + 2 * 8 * 256 * 8 * 4
+    assert lib.esn_predict_workspace_bytes(F16, C.byref(sh), 150, 75) == 0       # N_res = 512: persistent kernels
     assert lib.esn_readout_solve_workspace_bytes(3, 128, 528, 8) == 3 * 8 * (128 * 528 + 8 * 528 + 2 * 128)
     assert lib.esn_readout_solve_workspace_bytes(1, 512, 104, 4) == 8 * ((104 + 4) * 512 + 4 * 512 + 2 * 104)
 
@@ -70,7 +76,7 @@ def test_argument_errors_are_reported(lib):
     assert lib.esn_tile_frames(F64, C.byref(bad)) < 0
     sh = Shape(8, 2, 2, 1, 1)
     rc = lib.esn_predict_batch(F64, C.byref(sh), None, None, None, None, None, None, None,
-                               1, 1, 4, 4, 0, None, None, 0.0, 0, None, 0, None, None)
+                               1, 1, 4, 4, 0, None, None, 0.0, 0, None, 0, None, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.esn_last_error()
     rc = lib.esn_detect_count(1, 1, 1, 100, 2, 4, 1, 1, 1, 1, None, None)
     assert rc == -1 and b"power of two" in lib.esn_last_error()

@@ -1,0 +1,83 @@
+"""Reservoirs beyond 1024 units (BASELINE configs[4], N_res = 2048): the launch-per-step GEMM path
+(csrc/esn_recur_big.hip) against the persistent fp16 kernel on identical inputs and identical noise
+draws (debug knob big_gemm=0), against the CPU oracle, and -- through tests/test_gpu_parity.py's c5 case
+-- against the reference's own predictions."""
+import numpy as np
+import pytest
+
+from oracle import esn_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, want):
+    return float(np.max(np.abs(got - want)) / (np.max(np.abs(want)) + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from esn_ofdm_mimo_amd import batched, _lib
+    return batched, _lib
+
+
+@pytest.mark.parametrize("n_res,n_in,n_out,G,F,precision", [(2048, 16, 8, 5, 75, "f16"), (1500, 4, 4, 3, 37, "f16"),
+                                                            (1100, 2, 2, 2, 301, "f16"), (2048, 16, 8, 2, 40, "bf16")])
+@pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3), ("tensor", 1e-3)])
+def test_big_gemm_path_matches_persistent_kernel(mods, n_res, n_in, n_out, G, F, precision, noise_mode, noise):
+    batched, lib = mods
+    rs = np.random.RandomState(n_res + G)
+    t_in, t, tr = 30, 34, 4
+    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=noise)
+    in_scale, in_shift = rs.rand(G, n_in) * 0.2 + 0.1, rs.randn(G, n_in) * 0.05
+    t_scale, t_shift = rs.rand(G, n_out) + 0.5, rs.randn(G, n_out) * 0.1
+    bank.set_scaling(in_scale, in_shift, t_scale, t_shift)
+    w_out = rs.randn(G, n_out, n_res + n_in) * 0.002          # weak feedback: rounding differences are not amplified
+    bank.set_readout(w_out)
+    B = G * F - 9                                             # last group is short
+    u = rs.randn(B, t_in, n_in)
+    x0, y0 = rs.randn(G, n_res) * 0.1, rs.randn(G, n_out) * 0.1
+    kw = dict(T=t, transient=tr, precision=precision, x0=x0, y0=y0, noise_mode=noise_mode, seed=5)
+    if noise_mode == "tensor":
+        if (n_res, precision) != (2048, "f16"):
+            pytest.skip("tensor noise: one shape is enough")
+        kw["noise_u"] = rs.rand(B, t, n_res)
+    from esn_ofdm_mimo_amd._lib import PRECISIONS
+    import ctypes as C
+    assert lib.load().esn_predict_workspace_bytes(PRECISIONS[precision], C.byref(bank.shape), B, F) > 0
+    big = bank.predict(u, F, **kw).cpu().numpy()
+    lib.debug_set("big_gemm", "0")
+    try:
+        persistent = bank.predict(u, F, **kw).cpu().numpy()
+    finally:
+        lib.debug_set("big_gemm", "1")
+    assert big.shape == persistent.shape == (B, t - tr, n_out)
+    tol = 2e-3 if precision == "f16" else 2e-2
+    assert rel_err(big, persistent) < tol, rel_err(big, persistent)
+    if noise == 0.0:
+        for b in (0, F - 1, F, B - 1):
+            grp = b // F
+            o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[grp], input_shift=in_shift[grp],
+                             teacher_scaling=t_scale[grp], teacher_shift=t_shift[grp], random_state=1)
+            o.W, o.W_in, o.W_feedb, o.W_out = w, w_in, w_fb, w_out[grp]
+            o.laststate, o.lastoutput = x0[grp], y0[grp]
+            want = o.predict(np.vstack([u[b], np.zeros((t - t_in, n_in))]), tr, continuation=True)
+            assert rel_err(big[b], want) < (2e-2 if precision == "f16" else 1e-1), (b, rel_err(big[b], want))
+
+
+def test_big_gemm_single_frame_and_no_workspace(mods):
+    """One frame (255 padding slots), and the C ABI's NULL-workspace contract: persistent kernel, same result."""
+    batched, lib = mods
+    rs = np.random.RandomState(3)
+    n_in, n_out, n_res = 16, 8, 2048
+    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=0.0)
+    bank.set_readout(rs.randn(1, n_out, n_res + n_in) * 0.002)
+    u = rs.randn(1, 20, n_in) * 0.1
+    a = bank.predict(u, 1, transient=2, precision="f16", noise_mode="none").cpu().numpy()
+    lib.debug_set("big_gemm", "0")
+    try:
+        b = bank.predict(u, 1, transient=2, precision="f16", noise_mode="none").cpu().numpy()
+    finally:
+        lib.debug_set("big_gemm", "1")
+    assert rel_err(a, b) < 2e-3
