@@ -44,6 +44,26 @@ class LinkParams:
     min_delay: int = 0
     f_d: float = 100.0
     channel: str = "tdlb"         # "tdlb" | "exp" | "awgn"
+    # driver variants (defaults = the north-star 4x8 driver: d = (Min+Max)//2, nForget = d + CP, fresh state)
+    delay_fixed: int = -1         # >= 0: output delay d of the trainer (the SISO driver trains without delay)
+    forget_fixed: int = -1        # >= 0: rows dropped from the fit and from every prediction
+    continuation: bool = False    # True: every predict starts from the training-final state / teacher output
+    coherence_fixed: int = 0      # > 0: data symbols per pilot instead of the Doppler formula
+
+    @classmethod
+    def siso_awgn(cls, n_sub=512, symbols_per_pilot=400):
+        """Demo_SISO_QPSK_AWGN_LDPC_ESN_with_ZF_LS.py: 1x1, QPSK, N=512, CP=0 (:107-111), flat unit-modulus
+        channel drawn once per Eb/No point (:203-206), `esn.fit(Ein, Eout)` with transient 0 and no output
+        delay (:224-226), `esn.predict(ESN_input)` = continuation=True (:253-254), 400 symbols per pilot."""
+        return cls(n_t=1, n_r=1, n_sub=n_sub, m=2, isi=1, channel="awgn", delay_fixed=0, forget_fixed=0,
+                   continuation=True, coherence_fixed=symbols_per_pilot)
+
+    @classmethod
+    def block_fading(cls, n_t=2, n_r=2, n_sub=512):
+        """OFDM_{SISO,SIMO_1-2,MIMO_2-2}_NBF_LDPC.py / Demo_MIMO_4x8_ChannelRank_..._fast.py: exponential-PDP
+        Rayleigh taps exp(-k/(CP/9)) redrawn every coherence block (:162-164,:272-279), 16-QAM, same trainer
+        as the 4x8 driver (delay (0+6)//2 = 3, nForget = 10)."""
+        return cls(n_t=n_t, n_r=n_r, n_sub=n_sub, m=4, isi=8, channel="exp")
 
     @property
     def cp(self):
@@ -55,7 +75,11 @@ class LinkParams:
 
     @property
     def delay(self):
-        return (self.min_delay + self.max_delay) // 2
+        return self.delay_fixed if self.delay_fixed >= 0 else (self.min_delay + self.max_delay) // 2
+
+    @property
+    def forget(self):
+        return self.forget_fixed if self.forget_fixed >= 0 else self.delay + self.cp
 
     @property
     def t_frame(self):
@@ -63,6 +87,8 @@ class LinkParams:
 
     @property
     def coherence_symbols(self):
+        if self.coherence_fixed > 0:
+            return self.coherence_fixed
         t_sym = (self.n_sub + self.isi - 1) / self.fs
         return max(1, math.floor((0.5 / max(self.f_d, 1e-9)) / t_sym))
 
@@ -256,15 +282,24 @@ class DetectorSweep:
         D = torch.zeros((g, t + d, self.n_out), dtype=torch.float64, device=self.device)
         U[:, :t] = _view_real(pilot_y)
         D[:, d:d + t] = _view_real(pilot_x)
-        self._fit_io = (U, D, d + p.cp)
+        self._fit_io = (U, D, p.forget)
         # float32 extended states on the all-GPU fast path (fp16/bf16 harvest + Cholesky): the state
         # columns are exactly representable, the fit is unchanged to ~1e-7
-        rows, cols = t + d - (d + p.cp), self.bank.n_reservoir + self.n_in
+        rows, cols = t + d - p.forget, self.bank.n_reservoir + self.n_in
         chol = self.solve_method == "chol" or (self.solve_method == "auto" and min(rows, cols) <= 128
                                                and self.n_out <= 8)
         e_dtype = "f32" if (chol and self.fit_precision in ("f16", "bf16")) else "f64"
-        return self.bank.fit(U, D, transient=d + p.cp, precision=self.fit_precision, noise_mode="counter",
-                             seed=seed, method=self.solve_method, e_dtype=e_dtype)
+        E = self.bank.fit(U, D, transient=p.forget, precision=self.fit_precision, noise_mode="counter",
+                          seed=seed, method=self.solve_method, e_dtype=e_dtype)
+        self._cont = None
+        if p.continuation:      # laststate / lastoutput of pyESN.py:195-197: training-final state, scaled teacher
+            y_last = D[:, -1, :]
+            if self.bank.t_scale is not None:
+                y_last = y_last * self.bank.t_scale[:g]
+            if self.bank.t_shift is not None:
+                y_last = y_last + self.bank.t_shift[:g]
+            self._cont = (E[:, -1, :self.bank.n_reservoir].double().contiguous(), y_last.contiguous())
+        return E
 
     def repair_fit(self, E):
         """Host-synchronising check of the last fit: groups the Cholesky path flagged are re-solved
@@ -280,7 +315,8 @@ class DetectorSweep:
         in-kernel) -> fused FFT/slicer/count."""
         p = self.p
         U = _view_real(data_y)
-        y = self.bank.predict(U, frames_per_block, T=p.t_frame + p.delay, transient=p.delay + p.cp,
+        x0, y0 = self._cont if (p.continuation and getattr(self, "_cont", None)) else (None, None)
+        y = self.bank.predict(U, frames_per_block, T=p.t_frame + p.delay, transient=p.forget, x0=x0, y0=y0,
                               precision=self.precision, noise_mode="counter", seed=seed, out=out)
         self.bank.detect_count(y, data_bits, self.p_i, frames_per_block, p.n_sub, p.n_t, p.m, err=err, bits=bits)
         return y
@@ -332,7 +368,7 @@ def coded_ber_point(sweep, code, ebno_db, snr_idx, n_blocks, frames_per_block=No
     E = sweep.train(py, px, seed=seed + snr_idx)
     sweep.repair_fit(E)
     U = _view_real(dy)
-    y = sweep.bank.predict(U, F, T=p.t_frame + p.delay, transient=p.delay + p.cp, precision=sweep.precision,
+    y = sweep.bank.predict(U, F, T=p.t_frame + p.delay, transient=p.forget, precision=sweep.precision,
                            noise_mode="counter", seed=seed + snr_idx)
     e_esn, n_esn, xh = sweep.bank.detect_count(y, tx_bits, sweep.p_i, F, p.n_sub, p.n_t, p.m, want_xhat=True)
     x_esn = torch.view_as_complex(xh.view(G * F, p.n_sub, p.n_t, 2).contiguous())

@@ -132,6 +132,18 @@ def exp_pdp_taps(cfg: LinkConfig, rng):
     return c
 
 
+def flat_taps(cfg: LinkConfig, rng):
+    """One-tap channel of unit modulus and random phase per link, the SISO driver's
+    `H_true = randn + 1j randn; H_true /= abs(H_true)`
+    (Demo_SISO_QPSK_AWGN_LDPC_ESN_with_ZF_LS.py:205-206); rng is a RandomState."""
+    c = np.zeros((cfg.n_r, cfg.n_t, cfg.isi), dtype=np.complex128)
+    for nr in range(cfg.n_r):
+        for nt in range(cfg.n_t):
+            h = rng.randn() + 1j * rng.randn()
+            c[nr, nt, 0] = h / np.abs(h)
+    return c
+
+
 def modulate(bits, cfg: LinkConfig, ebno_db, const=None):
     """bits [N*m x N_t] -> (X [N x N_t], x_cp pre-PA, x_cp post-PA).
 
