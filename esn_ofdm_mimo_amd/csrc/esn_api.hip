@@ -15,6 +15,9 @@ size_t recur_f64_lds_bytes(int FB, int n_res, int n_in, int n_out);
 // esn_recur_f64_mfma.hip
 bool f64_mfma_geometry(int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_f64_mfma(const RecurParams& p, hipStream_t stream);
+// esn_recur_rs.hip
+bool rs_path_applies(int precision, const RecurParams& p);
+int launch_recur_rs(int precision, const RecurParams& p, size_t wo_rs_off, hipStream_t stream);
 // esn_recur_big.hip
 bool big_path_applies(int precision, const RecurParams& p);
 int big_slots(const RecurParams& p);
@@ -77,6 +80,8 @@ Knobs& knobs() {
         x.chol_skip = v ? atoi(v) : 0;
         v = getenv("ESN_F64_MFMA");
         x.f64_mfma = (v && v[0] == '0') ? 0 : 1;
+        v = getenv("ESN_RS");
+        x.rs = (v && v[0] == '0') ? 0 : 1;
         v = getenv("ESN_BIG_GEMM");
         x.big_gemm = (v && v[0] == '0') ? 0 : 1;
         return x;
@@ -145,6 +150,7 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "mfma_geom_f32")) { parse3(value, k.geom32); return 0; }
     if (!strcmp(key, "chol_skip")) { k.chol_skip = value ? atoi(value) : 0; return 0; }
     if (!strcmp(key, "f64_mfma")) { k.f64_mfma = (value && value[0] == '0') ? 0 : 1; return 0; }
+    if (!strcmp(key, "rs")) { k.rs = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "big_gemm")) { k.big_gemm = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }
@@ -277,6 +283,11 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
         return hip_fail(launch_recur_big(precision, p, wout_big_offset(precision, p.n_out, p.g), workspace,
                                          (hipStream_t)stream), "esn_predict_batch");
     }
+    // N_res 257..512, fp16/bf16: state in registers, one wave per SIMD (tiles of 128 slots like the skewed kernel)
+    if (knobs().rs && rs_path_applies(precision, p) &&
+        (size_t)n_frames * (T - transient) * p.n_out * 8 < 0x7fffffffu)
+        return hip_fail(launch_recur_rs(precision, p, wout_big_offset(precision, p.n_out, p.g), (hipStream_t)stream),
+                        "esn_predict_batch");
     int e = m64 ? launch_recur_f64_mfma(p, (hipStream_t)stream)
             : (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
                                      : launch_recur_mfma(precision, p, (hipStream_t)stream);

@@ -24,6 +24,8 @@ struct Geometry {
     int skew;        // predict: the two waves of a SIMD run one third of a step apart (esn_recur_mfma_impl.h)
     int big;         // fp16/bf16, N_res > 1024: the launch-per-step GEMM path (esn_recur_big.hip) serves this shape;
                      // the packed read-out then carries that path's image behind the persistent kernel's
+    int rs;          // fp16/bf16: the register-resident-state kernel (esn_recur_rs.hip) serves this shape; the packed
+                     // read-out then carries that kernel's image behind the persistent kernel's
     int m64;         // ESN_F64: 1 = the float64 matrix-pipe kernel (esn_recur_f64_mfma.hip) fits this shape;
     int Bt64;        //          then Mp..Ks, MT, NT describe ITS tiling, Bt64 its frames per tile and Bt
                      //          stays the tile of the vector-ALU kernel (esn_recur_f64.hip)
@@ -159,6 +161,7 @@ struct Knobs {
     int geom32[3];         // float32 predict tiling override
     int chol_skip;         // bit mask of Cholesky-solve phases to drop (tools/time_chol.py)
     int f64_mfma;          // 1 (default): float64 batches run on the matrix pipe; 0: vector-ALU kernel (A/B tests)
+    int rs;                // 1 (default): fp16/bf16 predict at N_res 257..512 runs the register-resident-state kernel
     int big_gemm;          // 1 (default): N_res > 1024 predict runs as one GEMM launch per step when a workspace is given
 };
 Knobs& knobs();

@@ -115,6 +115,7 @@ __host__ __device__ inline size_t packed_wout_persistent_bytes(int es, int n_out
     return (size_t)g.ro_parts * n_ot * 16 * g.Kp * es + 16;
 }
 size_t big_wout_image_bytes(int Mp);
+size_t rs_wout_image_bytes(int Kp);
 
 // Readout image for the 16x16 MFMA: [part][ot][64-byte k-group][lane][16 B] then a
 // 16-byte trailer {1/gain, gain, 0, 0} (float).  gain is a power of two that brings
@@ -175,6 +176,30 @@ __global__ __launch_bounds__(256) void pack_wout_mfma_kernel(const double* Wout,
         float* tr = reinterpret_cast<float*>(out + g.ro_parts * per_part * ES);
         tr[0] = (float)(1.0 / gain); tr[1] = (float)gain; tr[2] = 0.f; tr[3] = 0.f;
     }
+    if (ES == 2 && g.rs) {
+        // image of the register-resident-state kernel (esn_recur_rs.hip): A operand of the 32x32x16 MFMA,
+        // [k-group of 16][lane (row = lane & 31, h)][8 elements], k = 16 kg + 8 h + e natural; rows 0-7 hi, 8-15 lo
+        char* rsb = out + (packed_wout_persistent_bytes(ES, n_out, g) + 15) / 16 * 16;
+        T* rimg = reinterpret_cast<T*>(rsb);
+        const int nkg16 = g.Kp / 16;
+        for (int i = threadIdx.x; i < nkg16 * 512; i += blockDim.x) {
+            const int e = i & 7, lane = (i >> 3) & 63, kg = i >> 9;
+            const int o = lane & 31, k = 16 * kg + 8 * (lane >> 5) + e;
+            const int oo = o & 7;
+            double v = 0.0;
+            if (o < 16 && oo < n_out) {
+                if (k < n_res) v = wo[(size_t)oo * ncols + k] * gain;
+                else if (k >= g.kin && k < g.kin + n_in) v = wo[(size_t)oo * ncols + n_res + (k - g.kin)] * gain;
+            }
+            const T hi = (T)(float)v;
+            const T lo = (T)(float)(v - (double)(float)hi);
+            rimg[i] = o < 8 ? hi : lo;
+        }
+        if (threadIdx.x == 0) {
+            float* tr = reinterpret_cast<float*>(rsb + (size_t)nkg16 * 1024);
+            tr[0] = (float)(1.0 / gain); tr[1] = (float)gain; tr[2] = 0.f; tr[3] = 0.f;
+        }
+    }
     if (ES == 2 && g.big) {
         // image of the launch-per-step GEMM path (esn_recur_big.hip): A operand of a 32x32x16 MFMA whose B
         // operand is an accumulator tile -- [row tile of 32 k][k-step s2][lane (o = lane & 31, h)][8 elements],
@@ -222,6 +247,7 @@ size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Ge
         return f64_wout_offset(n_res, n_in, n_out) + (g.m64 ? sizeof(double) * (size_t)16 * g.Kp : 0);
     const int es = (precision == ESN_F32) ? 4 : 2;
     const size_t base = packed_wout_persistent_bytes(es, n_out, g);
+    if (g.rs) return (base + 15) / 16 * 16 + rs_wout_image_bytes(g.Kp);
     return g.big ? (base + 15) / 16 * 16 + big_wout_image_bytes(g.Mp) : base;
 }
 size_t wout_big_offset(int precision, int n_out, const Geometry& g) {

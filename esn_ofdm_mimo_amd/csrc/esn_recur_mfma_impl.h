@@ -508,6 +508,20 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                 for (int j = 0; j < 4; ++j) {
                     const int kg = kg0 + i + j;
                     const int t = (i + j) >> 1;
+#ifdef ESN_B_INTERLEAVE
+                    // B fragment nt is re-read for the next k-group right behind the MT MFMAs that used it: its
+                    // LDS latency then runs under the remaining MFMAs of this k-group (still one buffer per nt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) TR::mma32(acc[mt][nt], abuf[j][mt], bA[nt]);
+                        if (nt == NT - 1 && j % 2 == 1) { TR::mma16(yacc[0], ra[j - 1], rb0); TR::mma16(yacc[0], ra[j], rb1); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        bA[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + (kg + 1) * 32);
+                        if (nt < NT - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    loadA(abuf[j], kg + 4);
+#else
                     mma_all(abuf[j], bA);
                     if (j % 2 == 1) { TR::mma16(yacc[0], ra[j - 1], rb0); TR::mma16(yacc[0], ra[j], rb1); }
                     // Two pinned regions per k-group.  The loads may not move above the MFMAs: the
@@ -518,6 +532,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                     loadA(abuf[j], kg + 4);
                     loadB(bA, kg + 1);
+#endif
                     if (j % 2 == 0) {
                         rb0 = *reinterpret_cast<const u32x4*>(zrow0 + t * 64);
                         rb1 = *reinterpret_cast<const u32x4*>(zrow0 + (t + nk64H) * 64);
