@@ -81,7 +81,7 @@ Knobs& knobs() {
         v = getenv("ESN_F64_MFMA");
         x.f64_mfma = (v && v[0] == '0') ? 0 : 1;
         v = getenv("ESN_RS");
-        x.rs = (v && v[0] == '0') ? 0 : 1;
+        x.rs = (v && v[0] == '1') ? 1 : 0;          // opt-in: measured slower than the skewed LDS-state kernel
         v = getenv("ESN_BIG_GEMM");
         x.big_gemm = (v && v[0] == '0') ? 0 : 1;
         return x;
@@ -150,7 +150,7 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "mfma_geom_f32")) { parse3(value, k.geom32); return 0; }
     if (!strcmp(key, "chol_skip")) { k.chol_skip = value ? atoi(value) : 0; return 0; }
     if (!strcmp(key, "f64_mfma")) { k.f64_mfma = (value && value[0] == '0') ? 0 : 1; return 0; }
-    if (!strcmp(key, "rs")) { k.rs = (value && value[0] == '0') ? 0 : 1; return 0; }
+    if (!strcmp(key, "rs")) { k.rs = (value && value[0] == '1') ? 1 : 0; return 0; }
     if (!strcmp(key, "big_gemm")) { k.big_gemm = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }

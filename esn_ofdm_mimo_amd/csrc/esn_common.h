@@ -161,7 +161,8 @@ struct Knobs {
     int geom32[3];         // float32 predict tiling override
     int chol_skip;         // bit mask of Cholesky-solve phases to drop (tools/time_chol.py)
     int f64_mfma;          // 1 (default): float64 batches run on the matrix pipe; 0: vector-ALU kernel (A/B tests)
-    int rs;                // 1 (default): fp16/bf16 predict at N_res 257..512 runs the register-resident-state kernel
+    int rs;                // 1: fp16/bf16 predict at N_res 257..512 runs the register-resident-state kernel (default 0:
+                           // correct but 17 % slower than the skewed LDS-state kernel on MI355X)
     int big_gemm;          // 1 (default): N_res > 1024 predict runs as one GEMM launch per step when a workspace is given
 };
 Knobs& knobs();

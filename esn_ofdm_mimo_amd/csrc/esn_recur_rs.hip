@@ -169,34 +169,76 @@ __global__ __launch_bounds__(256) void recur_rs_kernel(RecurParams p, size_t wo_
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         p.Y, 0, (int)(((size_t)p.n_frames * out_rows * n_out * 8) < 0x7fffffffu ? ((size_t)p.n_frames * out_rows * n_out * 8) : 0x7fffffffu), 0x00020000);
 
-    // activation of a finished accumulator tile -> two B fragments of the NEW state (k-groups 2 rt, 2 rt + 1)
-    auto activate = [&](const f32x16& a, int rt, uint32_t key, u32x4& f0, u32x4& f1) {
-        u32x2 xq[4];
+    // Activation of a finished accumulator tile -> two B fragments of the NEW state (k-groups 2 rt, 2 rt + 1), cut
+    // into 32 slices of 4-6 vector instructions: slice `pos` is issued right behind MFMA `pos` of the NEXT tile and
+    // pinned there (sched_barrier), so every MFMA gap carries its share of the tanh / noise / pack work.  Left to
+    // itself the scheduler emits the activation in blocks of ~50 instructions and the matrix pipe idles meanwhile.
+    //   quad q = pos / 8 holds rows 8 q + 4 h + j (j = 0..3) of the tile; phases pos % 8:
+    //   0-1 exp2, 1-2 +1, 2-3 rcp, 3-4 tanh = 1 - 2 / (1 + 2^z) (+ noise bias), 4 noise hash, 5-6 noise, 7 pack;
+    //   phase 7 of quads 1 and 3 also runs the two v_permlane32_swap that complete a fragment.
+    constexpr bool PK_NOISE = NOISE == ESN_NOISE_COUNTER && std::is_same<TR, TraitsF16>::value;
+    typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const _Float16 c1s = (_Float16)(1024.0f * n_c1);
+    const h16x2 c1h = {c1s, c1s};
+    const float t_bias = PK_NOISE ? 1.0f + n_c0 - (float)c1s : 1.0f;
+    float az[4];                 // per-quad temporaries of the sliced activation
+    uint32_t asq = 0;
+    h16x2 aw01, aw23, at01, at23;
+    u32x2 axq[4];
+    auto act_slice = [&](auto pos_tag, const f32x16& ap, int rt, uint32_t key, u32x4& f0, u32x4& f1) {
+        constexpr int pos = decltype(pos_tag)::value;
+        if constexpr (pos < 32) {
+            constexpr int q = pos / 8, ph = pos % 8;
+            if constexpr (ph == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v[4];
+                for (int j = 0; j < 4; ++j) az[j] = ap[4 * q + j];
+                az[0] = __builtin_amdgcn_exp2f(az[0]); az[1] = __builtin_amdgcn_exp2f(az[1]);
+            } else if constexpr (ph == 1) {
+                az[2] = __builtin_amdgcn_exp2f(az[2]); az[3] = __builtin_amdgcn_exp2f(az[3]);
+                az[0] += 1.0f; az[1] += 1.0f;
+            } else if constexpr (ph == 2) {
+                az[2] += 1.0f; az[3] += 1.0f;
+                az[0] = __builtin_amdgcn_rcpf(az[0]); az[1] = __builtin_amdgcn_rcpf(az[1]);
+            } else if constexpr (ph == 3) {
+                az[2] = __builtin_amdgcn_rcpf(az[2]); az[3] = __builtin_amdgcn_rcpf(az[3]);
+                az[0] = fmaf(-2.0f, az[0], t_bias); az[1] = fmaf(-2.0f, az[1], t_bias);
+            } else if constexpr (ph == 4) {
+                az[2] = fmaf(-2.0f, az[2], t_bias); az[3] = fmaf(-2.0f, az[3], t_bias);
+                if (NOISE == ESN_NOISE_COUNTER) asq = noise_quad(key, (uint32_t)(rt * 8 + 2 * q + h));
+            } else if constexpr (ph == 5) {
+                if constexpr (PK_NOISE) {
+                    aw01 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x3C3C3C3Cu, asq, 0x04010400u));
+                    aw23 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x3C3C3C3Cu, asq, 0x04030402u));
+                    at01 = __builtin_convertvector(f32x2{az[0], az[1]}, h16x2);
+                    at23 = __builtin_convertvector(f32x2{az[2], az[3]}, h16x2);
+                } else if (NOISE == ESN_NOISE_COUNTER) {
+                    az[0] = fmaf((float)(asq & 0xffU), n_c1, az[0] + n_c0);
+                    az[1] = fmaf((float)((asq >> 8) & 0xffU), n_c1, az[1] + n_c0);
+                }
+            } else if constexpr (ph == 6) {
+                if constexpr (PK_NOISE) {
+                    const h16x2 x01 = __builtin_elementwise_fma(aw01, c1h, at01);
+                    const h16x2 x23 = __builtin_elementwise_fma(aw23, c1h, at23);
+                    axq[q] = u32x2{__builtin_bit_cast(uint32_t, x01), __builtin_bit_cast(uint32_t, x23)};
+                } else if (NOISE == ESN_NOISE_COUNTER) {
+                    az[2] = fmaf((float)((asq >> 16) & 0xffU), n_c1, az[2] + n_c0);
+                    az[3] = fmaf((float)(asq >> 24), n_c1, az[3] + n_c0);
+                }
+            } else {
+                if constexpr (!PK_NOISE) axq[q] = rs_pack4<typename TR::elem>(az[0], az[1], az[2], az[3]);
+                // lane (r, h) holds rows 8 q + 4 h + j; fragment kg = 2 rt + (q >> 1) wants k-local 8 h' .. 8 h' + 7 in
+                // lane (r, h'): half 0 keeps its even quad and receives the partner's, half 1 likewise with the odd one
+                if constexpr (q == 1 || q == 3) {
+                    u32x2 lo = axq[q - 1], hi = axq[q];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = TR::act(a[4 * q + j]);
-            if (NOISE == ESN_NOISE_COUNTER) {
-                const uint32_t sq = noise_quad(key, (uint32_t)(rt * 8 + 2 * q + h));
-                v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
-                v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
-                v[2] = fmaf((float)((sq >> 16) & 0xffU), n_c1, v[2] + n_c0);
-                v[3] = fmaf((float)(sq >> 24), n_c1, v[3] + n_c0);
+                    for (int w2 = 0; w2 < 2; ++w2) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(lo[w2], hi[w2], false, false);
+                        lo[w2] = sw[0]; hi[w2] = sw[1];
+                    }
+                    (q == 1 ? f0 : f1) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
             }
-            xq[q] = rs_pack4<typename TR::elem>(v[0], v[1], v[2], v[3]);
-        }
-        // lane (r, h) holds rows 8 q + 4 h + j; fragment kg = 2 rt + (q >> 1) wants k-local 8 h' .. 8 h' + 7 in lane
-        // (r, h'): lanes of half 0 keep q even and receive the partner's q even, half 1 likewise with q odd
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            u32x2 lo = xq[2 * pr], hi = xq[2 * pr + 1];
-#pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(lo[w2], hi[w2], false, false);
-                lo[w2] = sw[0]; hi[w2] = sw[1];
-            }
-            (pr == 0 ? f0 : f1) = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     };
 
@@ -204,55 +246,116 @@ __global__ __launch_bounds__(256) void recur_rs_kernel(RecurParams p, size_t wo_
     issue(std::integral_constant<int, 0>{}, true, 0);
     issue(std::integral_constant<int, 1>{}, true, 1);
     issue(std::integral_constant<int, 2>{}, true, 2);
-    int cnt = 0;                                          // running chunk number (ring slot = cnt & 3)
+    int cnt = 0;                                          // chunk number of the step's first chunk (ring slot = chunk & 3)
     f32x16 acc_a, acc_b;                                  // even / odd row tiles
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // chunk 0 has landed (chunks 1 and 2 may still fly)
+    __builtin_amdgcn_s_barrier();
+#ifdef ESN_STAMPS
+    unsigned long long rs_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
     for (int s = 0; s < p.S; ++s) {
+        ESN_STAMP(t_s0)
         uint32_t key = 0;
         if (NOISE == ESN_NOISE_COUNTER) key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s);
         f32x16 racc_lo, racc_hi;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { racc_lo[i] = 0.f; racc_hi[i] = 0.f; }
-        // A fragments: four in flight per wave out of the ring (static rotation; the LDS latency of a fragment
-        // runs under the three MFMAs ahead of it)
-        auto gemm_chunk = [&](const char* ab, f32x16& acc, auto bsel) {
-            u32x4 a[4];
-#pragma unroll
-            for (int kg = 0; kg < 3; ++kg) a[kg] = *reinterpret_cast<const u32x4*>(ab + kg * 1024);
-#pragma unroll
-            for (int kg = 0; kg < NKG; ++kg) {
-                if (kg + 3 < NKG) a[(kg + 3) & 3] = *reinterpret_cast<const u32x4*>(ab + (kg + 3) * 1024);
-                TR::mma32(acc, a[kg & 3], bsel(std::integral_constant<int, 0>{}, kg));
-            }
-        };
-        rs_for_seq([&](auto ci_tag) {
+        // Event E(c), once per chunk c: chunk c+1 has landed (this wave's 9 pieces: all but the 9 youngest VMEM
+        // ops -- those of chunk c+2 --, then everybody's: barrier) and, everybody being inside chunk c, the slot of
+        // chunk c-1 is refilled with chunk c+3.  Tile chunks run it in the MIDDLE of their MFMAs, so the A-fragment
+        // pipeline flows across chunk boundaries without draining; read-out chunks (conditional per wave) at their start.
+        auto event = [&](auto ci_tag) {
             constexpr int ci = decltype(ci_tag)::value;
-            // chunk `cnt` has landed (this wave's 9 pieces: all but the 18 youngest VMEM ops), then everybody's
-            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            ESN_STAMP(e0)
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            ESN_STAMP(e1)
             __builtin_amdgcn_s_barrier();
-            {   // refill the slot of chunk cnt-1 (everyone is past it) with chunk cnt + 3
-                constexpr int ahead = RS_RING - 1;
-                constexpr int cj = (ci + ahead) % NCH;
-                const bool on = s + (ci + ahead) / NCH < p.S;
-                issue(std::integral_constant<int, cj>{}, on, (cnt + ahead) & (RS_RING - 1));
-            }
-            const char* ab = ring + (size_t)(cnt & (RS_RING - 1)) * CH_STRIDE + lane16;
-            if constexpr (ci < NRT) {
+            ESN_STAMP(e2)
+#ifdef ESN_STAMPS
+            rs_acc[0] += e1 - e0; rs_acc[1] += e2 - e1;
+#endif
+            constexpr int ahead = RS_RING - 1;
+            constexpr int cj = (ci + ahead) % NCH;
+            const bool on = s + (ci + ahead) / NCH < p.S;
+            issue(std::integral_constant<int, cj>{}, on, (cnt + ci + ahead) & (RS_RING - 1));
+        };
+        // ---- the NRT tile chunks as ONE stream of NRT * NKG MFMA positions, A fragments RS_D ahead (static rotation
+        // of 8 buffers), activation slice of the previous tile pinned behind every MFMA ----
+        constexpr int RS_D = 6, MID = NKG / 2;
+        {
+            u32x4 a[8];
+            const char* slot_ptr[RS_RING];
+#pragma unroll
+            for (int i = 0; i < RS_RING; ++i) slot_ptr[i] = ring + (size_t)((cnt + i) & (RS_RING - 1)) * CH_STRIDE + lane16;
+#pragma unroll
+            for (int i = 0; i < RS_D; ++i) a[i] = *reinterpret_cast<const u32x4*>(slot_ptr[0] + i * 1024);
+            rs_for_seq([&](auto ci_tag) {
+                constexpr int ci = decltype(ci_tag)::value;
                 f32x16& acc = (ci & 1) ? acc_b : acc_a;
+                const f32x16& ap = (ci & 1) ? acc_a : acc_b;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                gemm_chunk(ab, acc, [&](auto, int kg) -> const u32x4& { return st[kg]; });
-                if constexpr (ci > 0)
-                    activate((ci & 1) ? acc_a : acc_b, ci - 1, key, sn[2 * (ci - 1)], sn[2 * (ci - 1) + 1]);
+                rs_for_seq([&](auto pos_tag) {
+                    constexpr int pos = decltype(pos_tag)::value;
+                    constexpr int pq = ci * NKG + pos;
+                    if constexpr (pos == MID) event(ci_tag);
+#ifndef RS_DIAG_NOLDS            // (diagnostic builds only: wrong results, timing of one ingredient)
+                    if constexpr (pq + RS_D < NRT * NKG) {
+                        constexpr int cj = (pq + RS_D) / NKG, kj = (pq + RS_D) % NKG;
+                        a[(pq + RS_D) & 7] = *reinterpret_cast<const u32x4*>(slot_ptr[cj & (RS_RING - 1)] + kj * 1024);
+                    }
+#endif
+                    TR::mma32(acc, a[pq & 7], st[pos]);
+#ifndef RS_DIAG_NOACT
+                    if constexpr (ci > 0) act_slice(pos_tag, ap, ci - 1, key, sn[2 * (ci > 0 ? ci - 1 : 0)], sn[2 * (ci > 0 ? ci - 1 : 0) + 1]);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }, std::make_index_sequence<NKG>{});
+            }, std::make_index_sequence<NRT>{});
+        }
+        ESN_STAMP(t_s1)
+        // ---- read-out chunks: NKG MFMAs against the NEW state, position `pos` takes k-group korder(pos) ----
+        auto run_chunk = [&](const char* ab, f32x16& acc, auto korder, auto act_tag, const f32x16& ap) {
+            constexpr bool ACT = decltype(act_tag)::value;
+            u32x4 a[4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const u32x4*>(ab + korder(i) * 1024);
+            rs_for_seq([&](auto pos_tag) {
+                constexpr int pos = decltype(pos_tag)::value;
+                if constexpr (pos + 3 < NKG) a[(pos + 3) & 3] = *reinterpret_cast<const u32x4*>(ab + korder(pos + 3) * 1024);
+                constexpr int kg = korder(pos);
+                TR::mma32(acc, a[pos & 3], kg < 2 * NRT ? sn[kg] : st[kg]);
+                if constexpr (ACT) act_slice(pos_tag, ap, NRT - 1, key, sn[2 * NRT - 2], sn[2 * NRT - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }, std::make_index_sequence<NKG>{});
+        };
+        auto k_natural = [](int pos) constexpr { return pos; };
+        // behind the last tile: k-groups 2 NRT - 2 and 2 NRT - 1 (that tile's own fragments) go last
+        auto k_readout = [](int pos) constexpr { return pos < 2 * NRT - 2 ? pos : (pos < 2 * NRT ? pos + 2 : pos - 2); };
+        const std::integral_constant<bool, true> with_act;
+        const std::integral_constant<bool, false> no_act;
+        rs_for_seq([&](auto j_tag) {
+            constexpr int j = decltype(j_tag)::value;
+            constexpr int ci = NRT + j;
+            event(std::integral_constant<int, ci>{});
+            const char* ab = ring + (size_t)((cnt + ci) & (RS_RING - 1)) * CH_STRIDE + lane16;
+            if constexpr (j == 0) {
+                // the activation of the last tile rides under the first read-out chunk (or runs alone in a wave that
+                // has no use for this group's image)
+                const f32x16& ap = ((NRT - 1) & 1) ? acc_b : acc_a;
+                if (gl == 0) {
+                    run_chunk(ab, racc_lo, k_readout, with_act, ap);
+                } else {
+                    rs_for_seq([&](auto pos_tag) { act_slice(pos_tag, ap, NRT - 1, key, sn[2 * NRT - 2], sn[2 * NRT - 1]); },
+                               std::make_index_sequence<32>{});
+                }
             } else {
-                if constexpr (ci == NRT)
-                    activate(((NRT - 1) & 1) ? acc_b : acc_a, NRT - 1, key, sn[2 * (NRT - 1)], sn[2 * (NRT - 1) + 1]);
-                constexpr int j = ci - NRT;
-                auto newstate = [&](auto, int kg) -> const u32x4& { return kg < 2 * NRT ? sn[kg] : st[kg]; };
-                if (j == gl) gemm_chunk(ab, racc_lo, newstate);
-                if (j == gh && gh != gl) gemm_chunk(ab, racc_hi, newstate);
+                if (j == gl) run_chunk(ab, racc_lo, k_natural, no_act, racc_lo);
+                if (j == gh && gh != gl) run_chunk(ab, racc_hi, k_natural, no_act, racc_hi);
             }
-            ++cnt;
-        }, std::make_index_sequence<NCH>{});
+        }, std::make_index_sequence<RS_GC>{});
+        cnt += NCH;
+        ESN_STAMP(t_s2)
         // ---- step boundary: Y_{s+1} = W_out [X_{s+1} ; U_s] -> output row s, F_{s+1}; next inputs; state swap ----
         float y4[4];
 #pragma unroll
@@ -286,7 +389,15 @@ __global__ __launch_bounds__(256) void recur_rs_kernel(RecurParams p, size_t wo_
         load_in(s + 2, in_next);
 #pragma unroll
         for (int kg = 0; kg < 2 * NRT; ++kg) st[kg] = sn[kg];
+        ESN_STAMP(t_s3)
+#ifdef ESN_STAMPS
+        rs_acc[2] += t_s1 - t_s0; rs_acc[3] += t_s2 - t_s1; rs_acc[4] += t_s3 - t_s2;
+#endif
     }
+#ifdef ESN_STAMPS
+    if (p.stamps && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 5; ++i) p.stamps[wave * 8 + i] = rs_acc[i];
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (drain the out-of-range tail DMAs before the LDS is released)
 }
 

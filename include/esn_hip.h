@@ -84,8 +84,8 @@ int esn_abi_version(void);
  *   "mfma_geom_f32" the table's padded row count, so a packed image never goes stale; NULL = table
  *   "chol_skip"     bit mask of Cholesky-solve phases to drop (timing only, wrong results)
  *   "f64_mfma"      "0" = ESN_F64 batches on the vector-ALU kernel instead of the float64 matrix pipe
- *   "rs"            "0" = fp16/bf16 predict at N_res 257..512 on the LDS-state (skewed) kernel instead of the
- *                   register-resident-state kernel
+ *   "rs"            "1" = fp16/bf16 predict at N_res 257..512 on the register-resident-state kernel
+ *                   (esn_recur_rs.hip; an experiment kept for A/B runs) instead of the skewed LDS-state kernel
  *   "big_gemm"      "0" = N_res > 1024 predict on the persistent kernel even when a workspace is given
  * Returns 0, or -1 for an unknown key. */
 int esn_debug_set(const char* key, const char* value);

@@ -1,6 +1,7 @@
 """Register-resident-state fp16 / bf16 predict kernel (csrc/esn_recur_rs.hip; N_res 257..512, n_in 13..16,
-n_out <= 8: the headline shape) against the LDS-state kernel on identical inputs and identical noise draws
-(debug knob rs=0) and against the CPU oracle."""
+n_out <= 8: the headline shape; opt-in by the debug knob rs=1 -- it is correct but measured slower than the
+default) against the LDS-state kernel on identical inputs and identical noise draws and against
+the CPU oracle."""
 import numpy as np
 import pytest
 
@@ -40,12 +41,12 @@ def test_register_state_kernel_matches_lds_state_kernel(mods, n_res, n_in, n_out
     u = rs.randn(B, t_in, n_in)
     x0, y0 = rs.randn(G, n_res) * 0.1, rs.randn(G, n_out) * 0.1
     kw = dict(T=t, transient=tr, precision=precision, x0=x0, y0=y0, noise_mode=noise_mode, seed=5)
-    new = bank.predict(u, F, **kw).cpu().numpy()
-    lib.debug_set("rs", "0")
+    old = bank.predict(u, F, **kw).cpu().numpy()
+    lib.debug_set("rs", "1")
     try:
-        old = bank.predict(u, F, **kw).cpu().numpy()
+        new = bank.predict(u, F, **kw).cpu().numpy()
     finally:
-        lib.debug_set("rs", "1")
+        lib.debug_set("rs", "0")
     assert new.shape == old.shape == (B, t - tr, n_out)
     tol = (2e-3 if noise == 0.0 else 8e-3) * (1 if precision == "f16" else 10)
     assert rel_err(new, old) < tol, rel_err(new, old)

@@ -50,6 +50,13 @@ for _ in range(2):
     sweep.bank.predict(U, F, T=T, transient=params.delay + params.cp, precision=prec, noise_mode="counter", seed=3)
 torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(16, 8)
+if os.environ.get("ESN_RS", "1") != "0" and prec in ("f16", "bf16"):
+    print("register-state kernel: cycles per timestep (workgroup 0), per wave")
+    print("wave   event: vmcnt wait   event: barrier     tile chunks    read-out chunks   boundary      total")
+    for w in range(4):
+        v = raw[w, :5].astype(float) / T
+        print(f"{w:4d} {v[0]:18.0f} {v[1]:16.0f} {v[2]:15.0f} {v[3]:18.0f} {v[4]:10.0f} {v[2] + v[3] + v[4]:10.0f}")
+    sys.exit(0)
 hw = raw[:8, 6]
 print("HW_ID per wave: " + " ".join(f"w{w}:simd{(int(v) >> 4) & 3}/cu{(int(v) >> 8) & 15}" for w, v in enumerate(hw)))
 st = raw[:8, :6].astype(float) / T

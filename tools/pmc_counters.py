@@ -31,6 +31,8 @@ PASSES = [
     ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
      "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES"],
     ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCP_TCC_READ_REQ_sum"],
+    ["SQC_ICACHE_REQ", "SQC_ICACHE_HITS", "SQC_ICACHE_MISSES", "SQ_IFETCH", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS",
+     "SQ_INSTS_LDS", "SQ_WAVE_CYCLES"],
 ]
 
 
@@ -76,6 +78,8 @@ def main():
                     m[c.lower() + "_frac"] = m[c] / w
         if m.get("SQ_LDS_IDX_ACTIVE"):
             m["lds_conflict_frac"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
+        if m.get("SQC_ICACHE_REQ"):
+            m["icache_miss_frac"] = m.get("SQC_ICACHE_MISSES", 0.0) / m["SQC_ICACHE_REQ"]
         if m.get("TCC_HIT_sum") is not None and (m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)) > 0:
             m["l2_hit"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
         out["kernels"][kc] = m
