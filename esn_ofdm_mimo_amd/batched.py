@@ -29,7 +29,10 @@ def _as_dev(x, torch, device, dtype=None):
     if isinstance(x, torch.Tensor):
         t = x.to(device=device, dtype=dtype or torch.float64)
     else:
-        t = torch.as_tensor(np.ascontiguousarray(x), device=device).to(dtype or torch.float64)
+        a = np.ascontiguousarray(x)
+        if not a.flags.writeable:                 # (arrays out of an .npz are read-only; torch wants ownership)
+            a = a.copy()
+        t = torch.as_tensor(a, device=device).to(dtype or torch.float64)
     return t.contiguous()
 
 

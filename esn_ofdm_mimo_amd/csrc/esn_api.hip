@@ -322,6 +322,8 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     const bool m64 = use_f64_mfma(precision, p, n_groups);
     const int tile = m64 ? p.g.Bt64 : p.g.Bt;
     p.Fpad = (p.n_wsets == 1) ? 1 : tile;   // shared reservoir: tiles span groups
+    // (Tried: leaving slots empty so that 2048 pilots spread over 256 tiles of 8 instead of 64 tiles of 32 -- the
+    //  harvest is bound by the AGGREGATE L2 weight stream, 4x the workgroups stream 4x the bytes: 1.14 -> 1.23 ms.)
     if (p.n_wsets == 1 && !m64) shrink_f64_tile(precision, p);
     p.n_tiles = (int)(((long long)n_groups * p.Fpad + (m64 ? tile : p.g.Bt) - 1) / (m64 ? tile : p.g.Bt));
     p.T_in = T; p.S = T - 1; p.in_row_off = 1; p.transient = 0; p.harvest = 1;
