@@ -28,6 +28,7 @@ headline (fp16 operands, shared reservoir) the same line carries, measured in th
 the same workload (N=1 only):
     `precisions`   the step in float32 (exact f32 MFMA) and float64 (the reference's arithmetic)
     `reservoirs`   the fp16 step with one reservoir per coherence block (reference-faithful mode)
+    `large_reservoir`  the fp16 step at N_res = 2048 (BASELINE configs[4]; one GEMM launch per timestep)
 `cpu_baseline` times the NumPy oracle (the reference algorithm, one frame per call, float64) on
 this host on bounded samples of the same workload: one BLAS thread, default BLAS threads, and one
 single-threaded process per core over disjoint block shards (`value`).
@@ -324,6 +325,19 @@ def main():
                                          reservoir="per_block: weight set = block index mod 8 (pool of 8 pre-drawn "
                                                    "reservoirs; the reference draws one per block, SURVEY F5)")
 
+    large = None
+    if not args.no_extra and world == 1 and not args.predict_only and args.n_res != 2048:
+        g_big = 512                                   # 512 x 80 slots = 160 frame tiles x 8 row tiles = 5 workgroups per CU
+        rec = run_config(torch, dist, params, precision=args.precision, fit_precision=args.fit_precision,
+                         reservoirs="shared", n_res=2048, G=g_big, steps=2, warmup=1, F=F, ebno=args.ebno,
+                         solve=args.solve, rank=rank, world=world)
+        large = {k: rec[k] for k in ("value", "ms_per_step", "predict_kernel_ms", "achieved_tflops", "peak", "frac", "ber",
+                                     "blocks", "frames_per_step", "fit_precision", "fit_groups_flagged", "flop_per_frame")}
+        large.update(unit="OFDM symbols/s", dtype=DTYPE_NAME[args.precision], steps=2, warmup=1,
+                     workload="configs[4]: 4x8 TDL-B, N=128, N_res=2048, shared reservoir",
+                     kernel="esn::big_prep_kernel + esn::big_step_kernel, one pair of launches per timestep "
+                            "(predict_kernel_ms spans all of them)")
+
     traffic, traffic_src = pmc_traffic(args.precision, G, F)
     if rank == 0:
         out = {
@@ -361,6 +375,8 @@ def main():
             out["precisions"] = extra_prec
         if extra_res:
             out["reservoirs"] = extra_res
+        if large:
+            out["large_reservoir"] = large
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

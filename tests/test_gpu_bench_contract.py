@@ -41,6 +41,7 @@ def test_bench_line_small_run():
         p_ = d["precisions"][prec]
         assert p_["value"] > 0 and p_["peak"] == peak and abs(p_["frac"] - p_["achieved_tflops"] / peak) < 1e-9
         assert 0.15 < p_["ber"] < 0.30
+    assert d["large_reservoir"]["value"] > 0 and 0.1 < d["large_reservoir"]["frac"] < 1 and 0.1 < d["large_reservoir"]["ber"] < 0.3
     assert d["reservoirs"]["per_block"]["value"] > 0 and 0.15 < d["reservoirs"]["per_block"]["ber"] < 0.30
     # the detector works: BER of the 4x8 ESN at 12 dB is ~0.23 for both the GPU and the oracle sample
     assert 0.15 < d["ber"] < 0.30
