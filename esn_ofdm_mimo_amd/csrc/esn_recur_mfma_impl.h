@@ -582,6 +582,9 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
                 if (NOISE == ESN_NOISE_TENSOR && fr >= 0)
                     nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
+                // (Tried: a packed-half odd Taylor series for tanh on small pre-activations -- 5 v_pk instructions per
+                //  PAIR instead of exp2/add/rcp/fma per value -- forced on: 13.24 -> 13.00 ms and 3e-3 instead of 7e-4
+                //  output error.  Phase E is not what its slots wait for; removed.)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
