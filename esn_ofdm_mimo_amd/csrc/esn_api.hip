@@ -262,10 +262,19 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     // 16-frame column granularity (MFMA kernels) or no padding at all (float64 kernel)
     const bool m64 = use_f64_mfma(precision, p, n_frames);
     const int tile = m64 ? p.g.Bt64 : p.g.Bt;
-    if (p.n_wsets > 1) p.Fpad = round_up(p.F, tile);
-    else p.Fpad = (precision == ESN_F64 && !m64) ? p.F : round_up(p.F, 16);
+    // slots per group: the readout's 16-frame column granularity (MFMA kernels) or no padding at all (float64
+    // vector-ALU kernel); with several weight sets the slot axis is set-major (esn_common.h: spw), so a tile
+    // packs the groups of ONE set back to back instead of padding every group to a whole tile
+    p.Fpad = (precision == ESN_F64 && !m64) ? p.F : round_up(p.F, 16);
     if (!m64) shrink_f64_tile(precision, p);
-    p.n_tiles = (int)(((long long)p.n_groups * p.Fpad + (m64 ? tile : p.g.Bt) - 1) / (m64 ? tile : p.g.Bt));
+    const int tslots = m64 ? tile : p.g.Bt;
+    if (p.n_wsets > 1) {
+        const int gpw = (p.n_groups + p.n_wsets - 1) / p.n_wsets;
+        p.spw = round_up(gpw * p.Fpad, tslots);
+        p.n_tiles = p.n_wsets * (p.spw / tslots);
+    } else {
+        p.n_tiles = (int)(((long long)p.n_groups * p.Fpad + tslots - 1) / tslots);
+    }
     p.T_in = T_in; p.S = T; p.in_row_off = 0; p.transient = transient; p.harvest = 0;
     p.packed_w = packed_w; p.packed_wout = packed_wout;
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
@@ -321,11 +330,18 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     p.F = 1;
     const bool m64 = use_f64_mfma(precision, p, n_groups);
     const int tile = m64 ? p.g.Bt64 : p.g.Bt;
-    p.Fpad = (p.n_wsets == 1) ? 1 : tile;   // shared reservoir: tiles span groups
+    p.Fpad = 1;                             // one pilot per group; tiles span groups (of one weight set: spw)
     // (Tried: leaving slots empty so that 2048 pilots spread over 256 tiles of 8 instead of 64 tiles of 32 -- the
     //  harvest is bound by the AGGREGATE L2 weight stream, 4x the workgroups stream 4x the bytes: 1.14 -> 1.23 ms.)
     if (p.n_wsets == 1 && !m64) shrink_f64_tile(precision, p);
-    p.n_tiles = (int)(((long long)n_groups * p.Fpad + (m64 ? tile : p.g.Bt) - 1) / (m64 ? tile : p.g.Bt));
+    const int tslots = m64 ? tile : p.g.Bt;
+    if (p.n_wsets > 1) {
+        const int gpw = (n_groups + p.n_wsets - 1) / p.n_wsets;
+        p.spw = round_up(gpw, tslots);
+        p.n_tiles = p.n_wsets * (p.spw / tslots);
+    } else {
+        p.n_tiles = (int)(((long long)n_groups + tslots - 1) / tslots);
+    }
     p.T_in = T; p.S = T - 1; p.in_row_off = 1; p.transient = 0; p.harvest = 1;
     p.packed_w = packed_w;
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;

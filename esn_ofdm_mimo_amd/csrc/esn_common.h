@@ -43,6 +43,9 @@ struct RecurParams {
     int F;                 // frames per group
     int Fpad;              // slots per group
     int n_wsets;
+    int spw;               // n_wsets > 1: slots per weight set (whole tiles); the slot axis is then SET-MAJOR -- set w
+                           // owns slots [w spw, (w+1) spw) holding its groups w, w + n_wsets, w + 2 n_wsets, ... at
+                           // Fpad slots each -- so a tile never mixes weight sets yet packs several groups; 0 = one set
     int T_in;              // valid input rows per frame
     int S;                 // recurrence steps
     int in_row_off;        // input row fed at step s is s + in_row_off (harvest: 1)
@@ -141,10 +144,26 @@ struct LdpcDecodeParams {
     long long* err; long long* bits;
 };
 
+// slot -> group (n_groups or beyond = none) and the position j inside the group's Fpad slots
+__device__ __forceinline__ int slot_group(const RecurParams& p, int slot, int& j) {
+    if (p.spw == 0) {
+        const int grp = slot / p.Fpad;
+        j = slot - grp * p.Fpad;
+        return grp;
+    }
+    const int w = slot / p.spw, ls = slot - w * p.spw;
+    const int gi = ls / p.Fpad;
+    j = ls - gi * p.Fpad;
+    const int grp = gi * p.n_wsets + w;
+    return (w < p.n_wsets) ? grp : p.n_groups;
+}
+__device__ __forceinline__ int slot_group(const RecurParams& p, int slot) { int j; return slot_group(p, slot, j); }
+// weight set of the tile that starts at slot0
+__device__ __forceinline__ int slot_wset(const RecurParams& p, int slot0) { return p.spw ? slot0 / p.spw : 0; }
 // slot -> frame index (or -1 for padding) and its group
 __device__ __forceinline__ int slot_frame(const RecurParams& p, int slot, int& grp) {
-    grp = slot / p.Fpad;
-    const int j = slot - grp * p.Fpad;
+    int j;
+    grp = slot_group(p, slot, j);
     const int fr = grp * p.F + j;
     return (j < p.F && grp < p.n_groups && fr < p.n_frames) ? fr : -1;
 }

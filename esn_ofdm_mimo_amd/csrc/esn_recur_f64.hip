@@ -29,9 +29,9 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
         s_grp[tid] = grp;
     }
     __syncthreads();
-    int grp0 = slot0 / p.Fpad;
+    int grp0 = slot_group(p, slot0);
     if (grp0 >= p.n_groups) return;
-    const int wset = grp0 % p.n_wsets;
+    const int wset = slot_wset(p, slot0);
     const double* Wk = reinterpret_cast<const double*>(
         reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride);
     const int ncols = n_res + n_in;

@@ -71,9 +71,9 @@ __global__ __launch_bounds__(512) void recur_f64_mfma_kernel(RecurParams p) {
     int* tab_grp = tab_fr + BT;                                                    // [BT]
 
     const int slot0 = blockIdx.x * BT;
-    const int grp0 = slot0 / p.Fpad;
+    const int grp0 = slot_group(p, slot0);
     if (grp0 >= p.n_groups) return;
-    const int wset = grp0 % p.n_wsets;
+    const int wset = slot_wset(p, slot0);
     for (int i = tid; i < BT; i += NTH) { int gg; tab_fr[i] = slot_frame(p, slot0 + i, gg); tab_grp[i] = gg; }
     __syncthreads();
     for (int i = tid; i < BT * g.Ks; i += NTH) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void recur_f64_mfma_kernel(RecurParams p) {
     };
     // readout: this wave's column tile and K slice
     const int ro_ct = wave % NT, ro_part_id = wave / NT;
-    const int ro_grp = __builtin_amdgcn_readfirstlane((slot0 + ro_ct * 16) / p.Fpad);
+    const int ro_grp = __builtin_amdgcn_readfirstlane(slot_group(p, slot0 + ro_ct * 16));
     const bool ro_on = !HARVEST && ro_grp < p.n_groups;
     const char* wo_img = reinterpret_cast<const char*>(p.packed_wout) + (size_t)(ro_on ? ro_grp : 0) * p.wout_stride + p.wo64_off;
     const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(

@@ -155,9 +155,9 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
 
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
     const int slot0 = tile * BT;
-    const int grp0 = slot0 / p.Fpad;
+    const int grp0 = slot_group(p, slot0);
     if (grp0 >= p.n_groups) return;
-    const int wset = grp0 % p.n_wsets;
+    const int wset = slot_wset(p, slot0);
     const char* wp = reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride
                      + ((size_t)(wave * MT) * nkg * 64 + lane) * 16;
 
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     for (int i = tid; i < BT; i += NTHREADS) { int gtmp; tab_fr[i] = slot_frame(p, slot0 + i, gtmp); }
     for (int i = tid; i < NOWN * kin_p; i += NTHREADS) {
         const int c16 = i / kin_p, c = i % kin_p;
-        const int cg = (slot0 + c16 * 16) / p.Fpad;
+        const int cg = slot_group(p, slot0 + c16 * 16);
         float2 v = make_float2(0.f, 0.f);
         if (cg < p.n_groups && c < n_in) {
             v.x = p.in_scale ? (float)p.in_scale[(size_t)cg * n_in + c] : 1.f;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     }
     for (int i = tid; i < NOWN * 16; i += NTHREADS) {
         const int c16 = i / 16, o = i % 16;
-        const int cg = (slot0 + c16 * 16) / p.Fpad;
+        const int cg = slot_group(p, slot0 + c16 * 16);
         float2 v = make_float2(1.f, 0.f);
         if (cg < p.n_groups && o < n_out) {
             if (p.t_scale) v.x = (float)(1.0 / p.t_scale[(size_t)cg * n_out + o]);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         own[i] = c < NOWN;
         wop[i] = nullptr; wo_inv[i] = 1.f;
         if (!HARVEST && own[i]) {
-            const int cg = (slot0 + c * 16) / p.Fpad;
+            const int cg = slot_group(p, slot0 + c * 16);
             if (cg < p.n_groups) {
                 const char* base = reinterpret_cast<const char*>(p.packed_wout) + (size_t)cg * p.wout_stride;
                 wop[i] = base + (size_t)lane * 16;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         };
         // W_out fragments of the owned column tile, two trips ahead: ra[2i], ra[2i+1] = 64-byte
         // groups t and t + nk64H of the trips t = i (mod 2); `on` false: zeros, no traffic
-        const int own_grp = __builtin_amdgcn_readfirstlane((slot0 + wave * 16) / p.Fpad);
+        const int own_grp = __builtin_amdgcn_readfirstlane(slot_group(p, slot0 + wave * 16));
         const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(reinterpret_cast<const char*>(p.packed_wout)
                               + (size_t)(own_grp < p.n_groups ? own_grp : 0) * p.wout_stride),
@@ -646,8 +646,10 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         const size_t in_frame_bytes = (size_t)in_stride * 8;
         // first frame of the tile (frames grow with the slot index): offsets stay below Bt frames' worth
         // of bytes however many frames a group has
-        const int j0 = slot0 - grp0 * p.Fpad;
-        size_t u_base_frame = j0 < p.F ? (size_t)grp0 * p.F + j0 : ((size_t)grp0 + 1) * p.F;
+        int j0;
+        slot_group(p, slot0, j0);
+        // (a padding slot at the head of the tile: the next group on this slot axis -- the next group of the same set)
+        size_t u_base_frame = j0 < p.F ? (size_t)grp0 * p.F + j0 : ((size_t)grp0 + (p.spw ? p.n_wsets : 1)) * p.F;
         if (u_base_frame >= (size_t)p.n_frames) u_base_frame = (size_t)p.n_frames - 1;   // tile of padding only
         for (int i = tid; i < BT; i += NTHREADS) {
             const int fr = tab_fr[i];

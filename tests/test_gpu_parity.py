@@ -491,3 +491,36 @@ def test_argument_validation_on_device(amd):
         bank.predict(np.zeros((2, 4, 2)), 2, transient=4, precision="f64")   # transient >= T
     with pytest.raises(ValueError):
         bank.predict(np.zeros((4, 4, 2)), 2, precision="f64")          # 2 groups, readout holds 1
+
+
+@pytest.mark.parametrize("precision,n_res,tol", [("f64", 48, 1e-9), ("f32", 48, 5e-3), ("f16", 512, 2e-2), ("f64", 512, 1e-9)])
+def test_weight_sets_share_tiles_set_major(amd, precision, n_res, tol):
+    """Reference-faithful mode with MORE groups than weight sets (group g uses set g % n_wsets, as the sweep's
+    pool of pre-drawn reservoirs does): the kernels lay the slot axis out set-major, so a tile packs several
+    groups of ONE set (20 groups over 8 sets: three per set for sets 0-3, two for sets 4-7; ragged last group).
+    Harvest + solve + predict per group against the oracle with that group's own weights."""
+    _, _, batched = amd
+    rs = np.random.RandomState(17)
+    n_in, n_out, t, G, F, S = 16, 8, 40, 20, 21, 8
+    ws = [eo.draw_weights(np.random.RandomState(300 + k), n_in, n_out, n_res, 0.9, 0.2) for k in range(S)]
+    bank = batched.ReservoirBank(n_in, n_out, n_res, np.stack([w[0] for w in ws]), np.stack([w[1] for w in ws]),
+                                 np.stack([w[2] for w in ws]), noise=0.0)
+    in_scale, t_scale = rs.rand(G, n_in) * 0.1 + 0.05, rs.rand(G, n_out) + 0.5
+    bank.set_scaling(in_scale, None, t_scale, None)
+    u = rs.randn(G, t, n_in)
+    d = np.tanh(u[:, :, :n_out] * 0.1 + 0.05 * np.roll(u[:, :, :n_out], 1, axis=1))
+    E = bank.harvest(u, d, precision=precision, noise_mode="none").cpu().numpy()
+    w_out = rs.randn(G, n_out, n_res + n_in) * 0.01
+    bank.set_readout(w_out)
+    B = G * F - 5
+    u2 = rs.randn(B, t, n_in)
+    got = bank.predict(u2, F, transient=3, precision=precision, noise_mode="none").cpu().numpy()
+    for g in (0, 7, 8, 13, 19):
+        o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[g], teacher_scaling=t_scale[g], random_state=1)
+        o.W, o.W_in, o.W_feedb = ws[g % S]
+        o.fit(u[g], d[g], 0)
+        assert rel_err(E[g], o._ext_states) < (1e-10 if precision == "f64" else 1e-2 if precision == "f16" else 1e-5), (g, precision)
+        o.W_out = w_out[g]
+        for b in (g * F, min(g * F + F - 1, B - 1)):
+            want = o.predict(u2[b], 3, continuation=False)
+            assert rel_err(got[b], want) < tol, (precision, g, b, rel_err(got[b], want))
