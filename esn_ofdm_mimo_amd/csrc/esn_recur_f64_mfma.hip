@@ -296,28 +296,42 @@ __global__ __launch_bounds__(512) void recur_f64_mfma_kernel(RecurParams p) {
 
         // ===== E: X_{s+1} = tanh(P) + noise (u - 1/2) ===============================================
         if (have_next) { commit_in(s + 1, pre_in); if (HARVEST) commit_t(pre_t); }
+        // short series when every pre-activation of the wave is small (the OFDM workload stays below 0.15),
+        // library tanh otherwise -- a wave-uniform choice, so neither path is predicated
+        double amax = 0.0;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int fcol = nt * 16 + c;
-            const int fr = tab_fr[fcol];
-            uint32_t key = 0;
-            const double* nz = nullptr;
-            if (p.noise_mode == ESN_NOISE_COUNTER && fr >= 0) key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s);
-            if (p.noise_mode == ESN_NOISE_TENSOR && fr >= 0) nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = (w_rt0 + mt) * 16 + q + 4 * i;
-                    double x = tanh(acc[mt][nt][i]);
-                    if (fr >= 0 && row < n_res) {
-                        if (p.noise_mode == ESN_NOISE_COUNTER) x += p.noise * ((double)noise_uniform(key, row) - 0.5);
-                        else if (p.noise_mode == ESN_NOISE_TENSOR) x += p.noise * (nz[row] - 0.5);
+                for (int i = 0; i < 4; ++i) amax = fmax(amax, fabs(acc[mt][nt][i]));
+        const bool small = __all(amax <= TANH64_SERIES_MAX) != 0;   // NaN compares false -> library path
+        auto activate = [&](auto series_tag) {
+            constexpr bool SERIES = decltype(series_tag)::value;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int fcol = nt * 16 + c;
+                const int fr = tab_fr[fcol];
+                uint32_t key = 0;
+                const double* nz = nullptr;
+                if (p.noise_mode == ESN_NOISE_COUNTER && fr >= 0) key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s);
+                if (p.noise_mode == ESN_NOISE_TENSOR && fr >= 0) nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = (w_rt0 + mt) * 16 + q + 4 * i;
+                        double x = SERIES ? tanh_f64_series(acc[mt][nt][i]) : tanh(acc[mt][nt][i]);
+                        if (fr >= 0 && row < n_res) {
+                            if (p.noise_mode == ESN_NOISE_COUNTER) x += p.noise * ((double)noise_uniform(key, row) - 0.5);
+                            else if (p.noise_mode == ESN_NOISE_TENSOR) x += p.noise * (nz[row] - 0.5);
+                        }
+                        Zt[(size_t)fcol * g.Ks + row] = x;
                     }
-                    Zt[(size_t)fcol * g.Ks + row] = x;
                 }
             }
-        }
+        };
+        if (small) activate(std::true_type{}); else activate(std::false_type{});
         __syncthreads();                                         // X_{s+1}, U_{s+1} (, F_{s+1}) complete
         if (HARVEST) {
             // E row s+1, state columns: wave w copies frames w, w+8, ...

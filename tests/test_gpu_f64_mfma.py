@@ -140,3 +140,34 @@ def test_teacher_forcing_off_and_tail_transient(mods):
             o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, teacher_forcing=False, random_state=1)
             o.W, o.W_in, o.W_feedb, o.W_out = w, w_in, w_fb, w_out[b // F]
             assert rel_err(got[b], o.predict(u[b], tr, continuation=False)) < 1e-10
+
+
+@pytest.mark.parametrize("amp", [0.005, 0.6])
+def test_predict_f64_series_and_library_tanh(mods, amp):
+    """The activation takes the 21st-order series when a wave's pre-activations are all below 0.25 and
+    the library routine otherwise (esn_common.h tanh_f64_series): amp=0.005 keeps every state below 0.2
+    (series everywhere, as on the OFDM workload), amp=0.6 drives some waves above (both paths in one
+    launch).  Either way the result is the oracle's to float64 round-off."""
+    batched, lib = mods
+    n_res, n_in, n_out, G, F, t = 512, 16, 8, 2, 40, 30
+    rs = np.random.RandomState(5)
+    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=0.0)
+    w_out = rs.randn(G, n_out, n_res + n_in) * 0.002
+    bank.set_readout(w_out)
+    u = rs.randn(G * F, t, n_in) * amp
+    u[F:] *= 0.005 / amp                                            # the second group is always small
+    got = bank.predict(u, F, T=t, precision="f64").cpu().numpy()
+    ref = _valu(lib, lambda: bank.predict(u, F, T=t, precision="f64").cpu().numpy())
+    assert rel_err(got, ref) < 1e-12, rel_err(got, ref)
+    peak = 0.0
+    for b in (0, F - 1, F, 2 * F - 1):
+        o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, random_state=1)
+        o.W, o.W_in, o.W_feedb, o.W_out = w, w_in, w_fb, w_out[b // F]
+        seen, step = [], o.step
+        o.step = lambda x, uu, y: seen.append(step(x, uu, y)) or seen[-1]
+        want = o.predict(u[b], 0, continuation=False)
+        assert rel_err(got[b], want) < 1e-12, (b, rel_err(got[b], want))
+        if b < F:
+            peak = max(peak, float(np.max(np.abs(seen))))
+    assert (peak < 0.2) == (amp < 0.1), peak                        # the case exercises the path it names
