@@ -231,19 +231,23 @@ __device__ __forceinline__ float noise_uniform(uint32_t k, uint32_t row) {
 
 // float32 tanh: odd Taylor polynomial below 0.3 (truncation < 2e-9 relative),
 // 1 - 2/(exp(2|x|)+1) above; both evaluated, selected per lane (no divergence).
-__device__ __forceinline__ float tanh_f32(float x) {
-    float ax = fabsf(x);
+constexpr float TANH32_SERIES_MAX = 0.3f;
+__device__ __forceinline__ float tanh_f32_series(float x) {
     float x2 = x * x;
     float p = -0.00886323552990220f;            // -1382/155925
     p = fmaf(p, x2, 0.0218694885361552f);      //  62/2835
     p = fmaf(p, x2, -0.0539682539682540f);     // -17/315
     p = fmaf(p, x2, 0.133333333333333f);       //  2/15
     p = fmaf(p, x2, -0.333333333333333f);      // -1/3
-    p = fmaf(p * x2, x, x);
+    return fmaf(p * x2, x, x);
+}
+__device__ __forceinline__ float tanh_f32(float x) {
+    float ax = fabsf(x);
+    float p = tanh_f32_series(x);
     float e = __expf(2.0f * ax);                // v_exp_f32 path
     float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);   // v_rcp_f32 (1 ulp), not an IEEE divide
     r = copysignf(r, x);
-    return ax < 0.3f ? p : r;
+    return ax < TANH32_SERIES_MAX ? p : r;
 }
 
 // float64 tanh on |x| <= TANH64_SERIES_MAX: the odd Maclaurin series through x^21 in Horner form (12 DP

@@ -71,6 +71,10 @@ struct TraitsF32 {
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
     }
     static __device__ __forceinline__ float act(float x) { return tanh_f32(x); }
+    // when every pre-activation of a wave is below TANH32_SERIES_MAX the select in tanh_f32 always takes the
+    // series: evaluate only that (bit-identical result, half the instructions)
+    static constexpr bool HAS_SMALL = true;
+    static __device__ __forceinline__ float act_small(float x) { return tanh_f32_series(x); }
 };
 
 struct TraitsF16 {
@@ -96,6 +100,8 @@ struct TraitsF16 {
         v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
     }
     static __device__ __forceinline__ float act(float z) { return tanh_prescaled(z); }   // weights carry 2 log2 e
+    static constexpr bool HAS_SMALL = false;
+    static __device__ __forceinline__ float act_small(float z) { return tanh_prescaled(z); }
 };
 
 struct TraitsBF16 {
@@ -121,6 +127,8 @@ struct TraitsBF16 {
         v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
     }
     static __device__ __forceinline__ float act(float z) { return tanh_prescaled(z); }   // weights carry 2 log2 e
+    static constexpr bool HAS_SMALL = false;
+    static __device__ __forceinline__ float act_small(float z) { return tanh_prescaled(z); }
 };
 
 template <typename TR, int NW, int MT, int NT, bool HARVEST, int NOISE, bool SKEW>
@@ -1062,44 +1070,63 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             }
             if (HARVEST) stage_teacher(s + 1);
         }
+        bool small = false;
+        if constexpr (TR::HAS_SMALL) {
+            float amax = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = nt * 32 + r;
-            const int fr = tab_fr[col];
-            uint32_t key = 0;
-            const double* nz = nullptr;
-            if (NOISE == ESN_NOISE_COUNTER)
-                key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
-            if (NOISE == ESN_NOISE_TENSOR && fr >= 0)
-                nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = (wave * MT + mt) * 32 + 8 * q + 4 * h;
-                    float v[4];
+                    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(acc[mt][nt][i]));
+            small = __all(amax < TANH32_SERIES_MAX) != 0;          // NaN compares false -> full routine
+        }
+        auto activate = [&](auto small_tag) {
+            constexpr bool SMALL = decltype(small_tag)::value;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[mt][nt][4 * q + j]);
-                    // (state rows >= n_res are padding: their columns of Wext / W_out are zero, so the
-                    //  noise they pick up is never read -- no masking needed)
-                    if (NOISE == ESN_NOISE_COUNTER) {
-                        // row/4 = (wave*MT*8 + h) + (mt*8 + 2q): the second term folds at compile time
-                        const uint32_t sq = noise_mix(key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U);
-                        // + noise*((byte+0.5)/256 - 0.5) = byte*n_c1 + n_c0
-                        v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
-                        v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
-                        v[2] = fmaf((float)((sq >> 16) & 0xffU), n_c1, v[2] + n_c0);
-                        v[3] = fmaf((float)(sq >> 24), n_c1, v[3] + n_c0);
-                    } else if (NOISE == ESN_NOISE_TENSOR) {
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = nt * 32 + r;
+                const int fr = tab_fr[col];
+                uint32_t key = 0;
+                const double* nz = nullptr;
+                if (NOISE == ESN_NOISE_COUNTER)
+                    key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
+                if (NOISE == ESN_NOISE_TENSOR && fr >= 0)
+                    nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = (wave * MT + mt) * 32 + 8 * q + 4 * h;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = SMALL ? TR::act_small(acc[mt][nt][4 * q + j]) : TR::act(acc[mt][nt][4 * q + j]);
+                        // (state rows >= n_res are padding: their columns of Wext / W_out are zero, so the
+                        //  noise they pick up is never read -- no masking needed)
+                        if (NOISE == ESN_NOISE_COUNTER) {
+                            // row/4 = (wave*MT*8 + h) + (mt*8 + 2q): the second term folds at compile time
+                            const uint32_t sq = noise_mix(key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U);
+                            // + noise*((byte+0.5)/256 - 0.5) = byte*n_c1 + n_c0
+                            v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
+                            v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
+                            v[2] = fmaf((float)((sq >> 16) & 0xffU), n_c1, v[2] + n_c0);
+                            v[3] = fmaf((float)(sq >> 24), n_c1, v[3] + n_c0);
+                        } else if (NOISE == ESN_NOISE_TENSOR) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+                        }
+                        TR::store4(zt + (size_t)col * row_bytes + (size_t)row * ES, v[0], v[1], v[2], v[3]);
                     }
-                    TR::store4(zt + (size_t)col * row_bytes + (size_t)row * ES, v[0], v[1], v[2], v[3]);
+                    // keep the scheduler from interleaving all 16*MT*NT activations (register pressure)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // keep the scheduler from interleaving all 16*MT*NT activations (register pressure)
-                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if constexpr (TR::HAS_SMALL) {
+            if (small) activate(std::true_type{}); else activate(std::false_type{});
+        } else {
+            activate(std::false_type{});
         }
         ESN_STAMP(t5)
         __syncthreads();                          // X_{s+1}, U_{s+1} (, F_{s+1}) complete

@@ -95,8 +95,11 @@ int esn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz,
                     char* arch_name, int arch_name_len);
 
 /* Frames per workgroup tile the recurrence kernel uses for this shape and
- * precision (>= 1); frames of one group are padded up to a multiple of it
- * inside the kernel, never in the caller's arrays. */
+ * precision (>= 1).  Padding happens inside the kernel, never in the caller's
+ * arrays: a group's frames are padded to a multiple of 16 (the MFMA column
+ * tile; no padding on the float64 vector-ALU path), and with n_wsets > 1 the
+ * groups of one weight set are laid end to end and that span is rounded up to
+ * whole tiles, so a tile streams one weight image and may serve several groups. */
 int esn_tile_frames(int precision, const esn_shape_t* shape);
 
 /* Bytes of the packed weight image for one weight set / one readout. */
