@@ -719,6 +719,9 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         // One program for both sets.  The readout runs in slot 3s+1 (P1 of set A, P0 of set B) and
         // yU_s in slot 3s+2 (P2 of set A, P1 of set B).
         const bool has_ro = __builtin_amdgcn_readfirstlane(wop[0] != nullptr ? 1 : 0) != 0;   // provably wave-uniform
+        // (Tried on the weight stream, all within +-1 % of 13.3 ms: cache-policy bits sc0 / nt / sc1 / sc1+sc0 on
+        //  the A loads (nt: +3 %), and starting the workgroups of an XCD up to one timestep apart so that the CUs
+        //  do not walk the image in lockstep.  The stream is not an L1 or an L2 hot-spot problem.)
         next_step_A();
         ro_prefetch(false);
         if (lag) __syncthreads();                                      // slot 0: set A alone
