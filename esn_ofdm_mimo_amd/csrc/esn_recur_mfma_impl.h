@@ -65,6 +65,9 @@ struct TraitsF32 {
         *reinterpret_cast<f32x4*>(dst) = v;
     }
     static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<float*>(dst) = v; }
+    static __device__ __forceinline__ void store2(char* dst, float v0, float v1) {
+        *reinterpret_cast<float2*>(dst) = make_float2(v0, v1);
+    }
     static __device__ __forceinline__ float load1(const char* src) { return *reinterpret_cast<const float*>(src); }
     static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 16-byte aligned
         const f32x4 t = *reinterpret_cast<const f32x4*>(src);
@@ -94,6 +97,10 @@ struct TraitsF16 {
         *reinterpret_cast<h16x4*>(dst) = v;
     }
     static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<_Float16*>(dst) = (_Float16)v; }
+    static __device__ __forceinline__ void store2(char* dst, float v0, float v1) {      // 4-byte aligned
+        typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<h16x2v*>(dst) = h16x2v{(_Float16)v0, (_Float16)v1};
+    }
     static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const _Float16*>(src); }
     static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 8-byte aligned
         const h16x4 t = *reinterpret_cast<const h16x4*>(src);
@@ -121,6 +128,10 @@ struct TraitsBF16 {
         *reinterpret_cast<b16x4*>(dst) = v;
     }
     static __device__ __forceinline__ void store1(char* dst, float v) { *reinterpret_cast<__bf16*>(dst) = (__bf16)v; }
+    static __device__ __forceinline__ void store2(char* dst, float v0, float v1) {      // 4-byte aligned
+        typedef __bf16 b16x2v __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<b16x2v*>(dst) = b16x2v{(__bf16)v0, (__bf16)v1};
+    }
     static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const __bf16*>(src); }
     static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 8-byte aligned
         const b16x4 t = *reinterpret_cast<const b16x4*>(src);
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     // ---- column ownership: wave owns tiles c_i = wave + i*NW (i < OC) of 16 frames each ------
     // readout view of a lane inside a 16x16 tile: frame column ofc, output rows 4*oq .. 4*oq+3
     const int oq = lane >> 4, ofc = lane & 15;
+    const int oq_w = oq, ofc_w = ofc;
     const char* wop[OC];          // this group's packed W_out (+ lane offset), nullptr = no readout
     float wo_inv[OC];
     bool own[OC];
@@ -392,6 +404,10 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
     };
     // Y complete: feedback rows into Zt, unscaled output row `orow` to HBM, reset yacc
     auto finish_readout = [&](int orow, bool write_fb) {
+        // (opaque copies of the lane coordinates when skewed: the addresses below are then derived here, once
+        //  per step, instead of living in registers across the GEMM phases of a kernel that has none to spare)
+        int ofc = ofc_w, oq = oq_w;
+        if (SKEW) asm volatile("" : "+v"(ofc), "+v"(oq));
 #pragma unroll
         for (int i = 0; i < OC; ++i) {
             if (!wop[i]) continue;
@@ -468,13 +484,23 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             const_cast<char*>(reinterpret_cast<const char*>(p.packed_w) + (size_t)wset * p.wset_stride), 0,
             (int)p.wset_stride, 0x00020000);
         const int w_row0 = wave * MT * nkg;
+#ifdef ESN_KO_A      // knock-out build (timing only, wrong results): no weight traffic, MFMAs on zeros
+        constexpr bool KO_A = true;
+#else
+        constexpr bool KO_A = false;
+#endif
         auto loadA = [&](u32x4 (&a)[MT], int kg) {       // kg >= nkg: no load, zeros
-            const bool live = kg < nkg;
+            const bool live = !KO_A && kg < nkg;
             const int voff = live ? lane16 : OOB;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 a[mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     w_rsrc, voff, live ? (w_row0 + mt * nkg + kg) * 1024 : 0, 0));
+        };
+        auto loadA1 = [&](u32x4& a, int mt, int kg) {    // one row tile's fragment of k-group kg
+            const bool live = !KO_A && kg < nkg;
+            a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                w_rsrc, live ? lane16 : OOB, live ? (w_row0 + mt * nkg + kg) * 1024 : 0, 0));
         };
         auto loadB = [&](u32x4 (&b)[NT], int kg) {
 #pragma unroll
@@ -502,6 +528,11 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             ra[2 * i + 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 wo_rsrc, voff, on ? (t + nk64H) * 1024 : 0, 0));
         };
+        auto load_ra1 = [&](u32x4& dst, int t, int part_off, bool on) {   // one half of load_ra
+            on = on && t < nk64H;
+            dst = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wo_rsrc, on ? lane16 : OOB, on ? (t + part_off) * 1024 : 0, 0));
+        };
         auto ro_prefetch = [&](bool on) { load_ra(0, 0, on); load_ra(1, 1, on); };
         // State k-groups [kg0, kg0 + nkgH) out of abuf, four per trip of the loop; abuf[j] holds group
         // kg0 + j on entry and kg0 + nkgH + j on exit (past the last [U;F] group: zeros -- the next
@@ -511,36 +542,18 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         auto gemm_half = [&](int kg0, bool ro_on) {
             loadB(bA, kg0);
             u32x4 rb0, rb1;
+#ifdef ESN_GEMM_BLOCKED
+            // (round-1 placement, kept for A/B runs: all MFMAs of the k-group, then all of its loads)
             for (int i = 0; i < nkgH; i += 4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int kg = kg0 + i + j;
                     const int t = (i + j) >> 1;
-#ifdef ESN_B_INTERLEAVE
-                    // B fragment nt is re-read for the next k-group right behind the MT MFMAs that used it: its
-                    // LDS latency then runs under the remaining MFMAs of this k-group (still one buffer per nt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) TR::mma32(acc[mt][nt], abuf[j][mt], bA[nt]);
-                        if (nt == NT - 1 && j % 2 == 1) { TR::mma16(yacc[0], ra[j - 1], rb0); TR::mma16(yacc[0], ra[j], rb1); }
-                        __builtin_amdgcn_sched_barrier(0);
-                        bA[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + (kg + 1) * 32);
-                        if (nt < NT - 1) __builtin_amdgcn_sched_barrier(0);
-                    }
-                    loadA(abuf[j], kg + 4);
-#else
                     mma_all(abuf[j], bA);
                     if (j % 2 == 1) { TR::mma16(yacc[0], ra[j - 1], rb0); TR::mma16(yacc[0], ra[j], rb1); }
-                    // Two pinned regions per k-group.  The loads may not move above the MFMAs: the
-                    // scheduler would give them new registers (A: eight live buffers instead of four;
-                    // B: double-buffered) and the kernel no longer fits 256 VGPRs.  The B fragments
-                    // are therefore single-buffered -- their LDS latency is covered by the other wave
-                    // of the SIMD when both run MFMAs, and hidden behind E otherwise.
                     __builtin_amdgcn_sched_barrier(0);
                     loadA(abuf[j], kg + 4);
                     loadB(bA, kg + 1);
-#endif
                     if (j % 2 == 0) {
                         rb0 = *reinterpret_cast<const u32x4*>(zrow0 + t * 64);
                         rb1 = *reinterpret_cast<const u32x4*>(zrow0 + (t + nk64H) * 64);
@@ -550,14 +563,98 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#else
+            // Hand-placed k-groups.  A wave issues in order and the SIMD issues about one instruction per four
+            // cycles for BOTH of its waves, so every instruction of this loop is paid twice: as matrix-pipe idle
+            // time when it sits between two MFMA bursts, and as an issue slot the partner wave's phase E does not
+            // get (knock-out builds, DESIGN 3.1b: with NO weight and NO state traffic the blocked loop still
+            // spent 440 cycles per k-group on 256 cycles of MFMAs).  Hence
+            //  * placement: the MFMAs run column-tile-major; B fragment nt is dead after its MT MFMAs and is
+            //    re-read for the next k-group right there, 6-7 MFMAs before its next use (single buffering is
+            //    enough); the A fragments are four k-groups ahead anyway and are refilled behind the last
+            //    column tile.  Every reload is pinned into the 32-cycle issue shadow of the MFMA that frees its
+            //    register -- no load above an MFMA that still reads its destination.  The readout pair of an
+            //    odd k-group goes first, so that the W_out fragments it read are refilled in the first shadows;
+            //  * count: addresses are running values stepped once per trip of four k-groups, the k-group's own
+            //    piece sits in the instruction's offset field, and nothing is conditional except in the last
+            //    trip of a half (the only one whose look-ahead can leave the image).
+            const int voff_ro = ro_on ? lane16 : OOB;
+            // LDS address of B fragment nt of k-group kg0 + i + 1
+            uint32_t bp[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bp[nt] = (uint32_t)(uintptr_t)(bbase + (size_t)nt * 32 * row_bytes + (kg0 + 1) * 32);
+            int sA[MT];                                      // A fragment of row tile mt, k-group kg0 + i + 4
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) sA[mt] = (w_row0 + mt * nkg + kg0 + 4) * 1024;
+            int sR0 = 2 * 1024, sR1 = (2 + nk64H) * 1024;   // W_out fragments two trips of the readout ahead
+            auto trip = [&](int i, auto tail_tag) {
+                constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kg = kg0 + i + j;
+                    const int t = (i + j) >> 1;
+                    if (j % 2 == 1) {
+                        TR::mma16(yacc[0], ra[j - 1], rb0);
+                        TR::mma16(yacc[0], ra[j], rb1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            TR::mma32(acc[mt][nt], abuf[j][mt], bA[nt]);
+                            const int m = nt * MT + mt;
+#ifndef ESN_KO_PURE  // knock-out build (timing only, wrong results): the k-group is its MFMAs and nothing else
+                            if (j % 2 == 0) {
+                                if (m == 0) rb0 = *reinterpret_cast<const u32x4*>(zrow0 + t * 64);
+                                if (m == 1) rb1 = *reinterpret_cast<const u32x4*>(zrow0 + (t + nk64H) * 64);
+                            } else if (TAIL) {
+                                if (m == 0) load_ra1(ra[j - 1], t + 2, 0, ro_on);
+                                if (m == 1) load_ra1(ra[j], t + 2, nk64H, ro_on);
+                            } else {
+                                if (m == 0) ra[j - 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                wo_rsrc, voff_ro, sR0 + (j >> 1) * 1024, 0));
+                                if (m == 1) ra[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                wo_rsrc, voff_ro, sR1 + (j >> 1) * 1024, 0));
+                            }
+                            if (nt == NT - 1) {
+                                if (TAIL) loadA1(abuf[j][mt], mt, kg + 4);
+                                else abuf[j][mt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                         w_rsrc, KO_A ? OOB : lane16, sA[mt] + j * 1024, 0));
+                            }
+                            if (mt == MT - 1) bA[nt] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
+                                                  (uintptr_t)(bp[nt] + j * 32));
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                // one step of the running addresses per trip
+                // (in place: left to itself the compiler keeps the base AND a stepped copy per fragment alive)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm volatile("v_add_u32 %0, 128, %0" : "+v"(bp[nt]));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) sA[mt] += 4096;
+                sR0 += 2048; sR1 += 2048;
+            };
+            for (int i = 0; i < nkgH - 4; i += 4) trip(i, std::false_type{});
+            trip(nkgH - 4, std::true_type{});
+#endif
         };
         auto uf_groups = [&]() {
             loadB(bA, nkgS);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < n_uf) {
-                    mma_all(abuf[j], bA);
-                    if (j + 1 < n_uf) loadB(bA, nkgS + j + 1);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {                // same placement as gemm_half
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) TR::mma32(acc[mt][nt], abuf[j][mt], bA[nt]);
+                        if (j + 1 < n_uf)
+                            bA[nt] = *reinterpret_cast<const u32x4*>(bbase + (size_t)nt * 32 * row_bytes + (nkgS + j + 1) * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         };
@@ -578,7 +675,9 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         const _Float16 c1s = (_Float16)(1024.0f * n_c1);
         const h16x2 c1h = {c1s, c1s};
         const float t_bias = 1.0f + n_c0 - (float)c1s;
-        auto activate = [&](int s, auto nt0_tag, auto nt1_tag, const int (&frs)[NT / 2]) {
+        auto activate = [&](int s, auto nt0_tag, auto nt1_tag, const int (&frs)[NT / 2], int r, int h) {
+            // (r, h: the lane coordinates, re-derived per step by the caller so that the store addresses
+            //  below are computed here and do not occupy registers across the GEMM phases)
             constexpr int NT0 = decltype(nt0_tag)::value, NT1 = decltype(nt1_tag)::value;
 #pragma unroll
             for (int nt = NT0; nt < NT1; ++nt) {
@@ -592,7 +691,9 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                     nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
                 // (Tried: a packed-half odd Taylor series for tanh on small pre-activations -- 5 v_pk instructions per
                 //  PAIR instead of exp2/add/rcp/fma per value -- forced on: 13.24 -> 13.00 ms and 3e-3 instead of 7e-4
-                //  output error.  Phase E is not what its slots wait for; removed.)
+                //  output error; and a float32 series z (a1 + a3 z^2 + a5 z^4) behind a wave-uniform vote: the same
+                //  four instructions per value as exp2/add/rcp/fma, and the transcendental unit runs beside the
+                //  plain ones, so the vote made it 2.5 % slower.  What phase E pays for is its instruction COUNT.)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -603,8 +704,12 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                             float t[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
+#ifdef ESN_KO_E      // knock-out build (timing only, wrong results): no transcendental work in phase E
+                                t[j] = acc[mt][nt][4 * q + j] + t_bias;
+#else
                                 const float e = __builtin_amdgcn_exp2f(acc[mt][nt][4 * q + j]);
                                 t[j] = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), t_bias);
+#endif
                             }
                             const uint32_t sq = noise_mix(key + (uint32_t)(mt * 8 + 2 * q) * 0x9E3779B9U);
                             const h16x2 w01 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(0x3C3C3C3Cu, sq, 0x04010400u));
@@ -673,17 +778,32 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
         // frames, lanes past the tile when n_in < 16, rows past T_in) get an out-of-range offset:
         // nothing is fetched, and whatever the DMA does with such a lane stays inside its own slot
         // (with tiles packed back to back those lanes landed in the neighbouring tile's rows).
+        // (Tried instead: carrying the rows in registers -- four 16-byte loads in the middle of phase E, converted
+        //  at the start of the next P0.  The four DMA launches below cost the issuing wave ~1.05 k cycles of its
+        //  phase E (stamps), but the 16 registers are not there: parked in a retired accumulator or not, the
+        //  kernel spills 19-36 VGPRs.)
         char* in_slots = reinterpret_cast<char*>(in_raw);
         auto dma_inputs_b = [&](int s) {
             const int row = s + p.in_row_off;
             const bool row_ok = row < p.T_in;
+            // straight-line: all frame offsets first (one LDS latency for the lot), then the launches; a trip
+            // past the tile (n_in < 8) has every lane out of range and fetches nothing
+            int off[IN_TILES][2];
+#pragma unroll
+            for (int ti = 0; ti < IN_TILES; ++ti)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int e = 64 * i + lane;
+                    off[ti][i] = tab_off[(in_c0 + ti) * 16 + ((e >> lcpf) & 15)];
+                }
 #pragma unroll
             for (int ti = 0; ti < IN_TILES; ++ti) {
                 const int c = in_c0 + ti;
-                for (int i = 0; 64 * i < 16 * cpf; ++i) {            // wave-uniform trip count (<= 2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
                     const int e = 64 * i + lane;
-                    const int off = (e < 16 * cpf) ? tab_off[c * 16 + (e >> lcpf)] : -1;
-                    const int voff = (off >= 0 && row_ok) ? off + ((e & (cpf - 1)) << 4) : OOB;
+                    const bool on = off[ti][i] >= 0 && row_ok && e < 16 * cpf;
+                    const int voff = on ? off[ti][i] + ((e & (cpf - 1)) << 4) : OOB;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         u_rsrc, (__attribute__((address_space(3))) void*)(in_slots + (size_t)(c * 2 + i) * 1024), 16,
                         voff, row_ok ? row * n_in * 8 : 0, 0, 0);
@@ -750,12 +870,14 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             __builtin_amdgcn_s_setprio(2);
             const u32x4 ra_u = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 wo_rsrc, has_ro ? lane16 : OOB, has_ro ? nk64S * 1024 : 0, 0));
+            int r_e = r, h_e = h;
+            asm volatile("" : "+v"(r_e), "+v"(h_e));               // opaque copies: see activate
             int frs[NT / 2];
 #pragma unroll
-            for (int i = 0; i < NT / 2; ++i) frs[i] = tab_fr[i * 32 + r];
+            for (int i = 0; i < NT / 2; ++i) frs[i] = tab_fr[i * 32 + r_e];
             uf_groups();
             ESN_STAMP(u1)
-            activate(s, nt_lo, nt_mid, frs);
+            activate(s, nt_lo, nt_mid, frs, r_e, h_e);
             ESN_STAMP(u2)
             {   // yU_s = Wout[:, inputs] U_s (the feedback columns of that group carry zero weights);
                 // U_s stays in Zt until set B commits U_{s+1} at the start of slot 3s+4
@@ -765,12 +887,12 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             next_step_A();
             ro_prefetch(lag && has_ro && s + 1 < p.S);                 // set B: for P0(s+1)
 #pragma unroll
-            for (int i = 0; i < NT / 2; ++i) frs[i] = tab_fr[(NT / 2 + i) * 32 + r];
+            for (int i = 0; i < NT / 2; ++i) frs[i] = tab_fr[(NT / 2 + i) * 32 + r_e];
             ESN_STAMP(u3)
             // last LDS read of the phase is behind us: the input DMA of step s+1 flies during the rest of E
             if (lag && s + 1 < p.S) dma_inputs_b(s + 1);
             ESN_STAMP(u4)
-            activate(s, nt_mid, nt_hi, frs);
+            activate(s, nt_mid, nt_hi, frs, r_e, h_e);
             ESN_STAMP(u5)
             __builtin_amdgcn_s_setprio(0);
             ESN_STAMP(t5)
