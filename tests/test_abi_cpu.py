@@ -51,7 +51,9 @@ def test_geometry_and_sizes(lib):
     assert lib.esn_packed_weights_bytes(BF16, C.byref(sh)) == 2 * 512 * 544
     assert lib.esn_packed_readout_bytes(F64, C.byref(sh)) == 8 * 8 * 528 + 8 * 16 * 536
     assert lib.esn_packed_readout_bytes(F32, C.byref(sh)) == 16 * 544 * 4 + 16
-    assert lib.esn_packed_readout_bytes(F16, C.byref(sh)) == 16 * 544 * 2 + 16   # hi rows 0-7, lo rows 8-15
+    # hi rows 0-7, lo rows 8-15; at this shape the image of the opt-in register-state kernel follows (34 fragments)
+    assert lib.esn_packed_readout_bytes(F16, C.byref(sh)) == (16 * 544 * 2 + 16) + (34 * 1024 + 16)
+    assert lib.esn_packed_readout_bytes(F16, C.byref(Shape(256, 16, 8, 1, 1))) == 16 * 288 * 2 + 16
     small = Shape(100, 2, 2, 1, 1)
     assert lib.esn_tile_frames(F32, C.byref(small)) == 64
     big = Shape(2048, 16, 8, 1, 1)
