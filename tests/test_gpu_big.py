@@ -14,6 +14,21 @@ def rel_err(got, want):
     return float(np.max(np.abs(got - want)) / (np.max(np.abs(want)) + 1e-300))
 
 
+_WEIGHTS = {}
+
+
+def draw_weights_cached(seed, n_in, n_out, n_res):
+    """eo.draw_weights (its eigvals of a 2048 x 2048 matrix takes 10-40 s of host time) once per shape and seed;
+    returns the weights and a RandomState continued from where the draw left it."""
+    key = (seed, n_in, n_out, n_res)
+    if key not in _WEIGHTS:
+        rs = np.random.RandomState(seed)
+        _WEIGHTS[key] = (eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1), rs.get_state())
+    rs = np.random.RandomState(0)
+    rs.set_state(_WEIGHTS[key][1])
+    return _WEIGHTS[key][0], rs
+
+
 @pytest.fixture(scope="module")
 def mods():
     from esn_ofdm_mimo_amd import batched, _lib
@@ -25,9 +40,8 @@ def mods():
 @pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3), ("tensor", 1e-3)])
 def test_big_gemm_path_matches_persistent_kernel(mods, n_res, n_in, n_out, G, F, precision, noise_mode, noise):
     batched, lib = mods
-    rs = np.random.RandomState(n_res + G)
+    (w, w_in, w_fb), rs = draw_weights_cached(n_res, n_in, n_out, n_res)
     t_in, t, tr = 30, 34, 4
-    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
     bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=noise)
     in_scale, in_shift = rs.rand(G, n_in) * 0.2 + 0.1, rs.randn(G, n_in) * 0.05
     t_scale, t_shift = rs.rand(G, n_out) + 0.5, rs.randn(G, n_out) * 0.1
@@ -68,9 +82,8 @@ def test_big_gemm_path_matches_persistent_kernel(mods, n_res, n_in, n_out, G, F,
 def test_big_gemm_single_frame_and_no_workspace(mods):
     """One frame (255 padding slots), and the C ABI's NULL-workspace contract: persistent kernel, same result."""
     batched, lib = mods
-    rs = np.random.RandomState(3)
     n_in, n_out, n_res = 16, 8, 2048
-    w, w_in, w_fb = eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1)
+    (w, w_in, w_fb), rs = draw_weights_cached(n_res, n_in, n_out, n_res)
     bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=0.0)
     bank.set_readout(rs.randn(1, n_out, n_res + n_in) * 0.002)
     u = rs.randn(1, 20, n_in) * 0.1
