@@ -34,7 +34,10 @@ typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 bool f64_mfma_geometry(int n_res, int n_in, int n_out, bool harvest, Geometry* g) {
     if (n_out > 16 || n_res > 1024) return false;
     const int MT = (n_res + 127) / 128;                  // 8 waves x 16 rows per row round
-    const int NT = (MT <= 4) ? 2 : 1;                    // accumulators: MT*NT*8 VGPRs <= 64
+    // accumulators: MT*NT*8 VGPRs <= 64.  The harvest takes 16-frame tiles whatever MT is: a fit has one pilot per
+    // trained ESN, a few hundred to a few thousand sequences, and the launch is 137 serial steps long -- twice the
+    // workgroups at half the MFMAs per step (512 pilots: 9.9 -> 5.x ms).
+    const int NT = (MT <= 4 && !harvest) ? 2 : 1;
     g->NW = 8; g->MT = MT; g->NT = NT;
     g->Mp = 128 * MT;
     g->kin = g->Mp;
@@ -409,6 +412,10 @@ int launch_recur_f64_mfma(const RecurParams& p, hipStream_t stream) {
         }
     } else if (g.NT == 1) {
         switch (g.MT) {
+            case 1: return launch_mt<1, 1>(p, stream);
+            case 2: return launch_mt<2, 1>(p, stream);
+            case 3: return launch_mt<3, 1>(p, stream);
+            case 4: return launch_mt<4, 1>(p, stream);
             case 5: return launch_mt<5, 1>(p, stream);
             case 6: return launch_mt<6, 1>(p, stream);
             case 7: return launch_mt<7, 1>(p, stream);
