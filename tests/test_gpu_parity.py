@@ -165,7 +165,8 @@ def test_ragged_batch_and_groups(amd, precision):
 
 
 @pytest.mark.parametrize("n_res,n_in,n_out,G,F", [(256, 16, 8, 5, 75), (512, 16, 8, 5, 75), (1024, 16, 8, 5, 75),
-                                                  (512, 4, 4, 5, 75), (512, 2, 2, 5, 75), (512, 16, 8, 2, 301)])
+                                                  (512, 4, 4, 5, 75), (512, 2, 2, 5, 75), (512, 16, 8, 2, 301),
+                                                  (384, 8, 6, 3, 37)])
 @pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3), ("tensor", 1e-3)])
 def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res, n_in, n_out, G, F):
     """The fp16 predict kernel of 8-wave tilings (N_res 256 / 512 / 1024: 128, 128 and 64 frames per
