@@ -414,22 +414,35 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             const int c = wave + i * NW;
             const int of = c * 16 + ofc;
             f32x4 y = yacc[i];
+            const int o0 = 4 * oq;
+            // the table reads first: their LDS latency runs under the fold below
+            const int fr = tab_fr[of];
+            const float4* un4 = reinterpret_cast<const float4*>(tab_un + c * 16 + o0);         // {1/scale, shift} x 4
+            const float4 u01 = un4[0], u23 = un4[1];
             if (g.ro_fold) {          // rows 8..15 (lanes 32..63) hold the residual image's product
+                // (a v_permlane32_swap of the value with itself would give both halves to every lane without the
+                //  trip through the LDS crossbar; tried here, it produced wrong sums -- not understood, not kept)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] += __shfl_xor(y[j], 32);
             }
             y *= wo_inv[i];
-            const int o0 = 4 * oq;
             if (o0 < kfb_p) {
                 if (write_fb)
                     TR::store4(zt + (size_t)of * row_bytes + (size_t)(g.kfb + o0) * ES, y[0], y[1], y[2], y[3]);
-                const int fr = tab_fr[of];
                 if (orow >= 0 && fr >= 0) {
                     double* yo = p.Y + ((size_t)fr * out_rows + orow) * n_out;
-                    const float2* un = tab_un + c * 16 + o0;               // {1/scale, shift}
+                    if ((n_out & 3) == 0) {                                // whole quads: two 16-byte stores
+                        typedef double f64x2s __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<f64x2s*>(yo + o0) =
+                            f64x2s{(double)((y[0] - u01.y) * u01.x), (double)((y[1] - u01.w) * u01.z)};
+                        *reinterpret_cast<f64x2s*>(yo + o0 + 2) =
+                            f64x2s{(double)((y[2] - u23.y) * u23.x), (double)((y[3] - u23.w) * u23.z)};
+                    } else {
+                        const float2* un = tab_un + c * 16 + o0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (o0 + j < n_out) yo[o0 + j] = (double)((y[j] - un[j].y) * un[j].x);
+                        for (int j = 0; j < 4; ++j)
+                            if (o0 + j < n_out) yo[o0 + j] = (double)((y[j] - un[j].y) * un[j].x);
+                    }
                 }
             }
             yacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
