@@ -801,12 +801,14 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             const bool row_ok = row < p.T_in;
             // straight-line: all frame offsets first (one LDS latency for the lot), then the launches; a trip
             // past the tile (n_in < 8) has every lane out of range and fetches nothing
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                       // opaque: derived per step, not kept across the GEMM phases
             int off[IN_TILES][2];
 #pragma unroll
             for (int ti = 0; ti < IN_TILES; ++ti)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int e = 64 * i + lane;
+                    const int e = 64 * i + ln;
                     off[ti][i] = tab_off[(in_c0 + ti) * 16 + ((e >> lcpf) & 15)];
                 }
 #pragma unroll
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                 const int c = in_c0 + ti;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int e = 64 * i + lane;
+                    const int e = 64 * i + ln;
                     const bool on = off[ti][i] >= 0 && row_ok && e < 16 * cpf;
                     const int voff = on ? off[ti][i] + ((e & (cpf - 1)) << 4) : OOB;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -824,22 +826,29 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
             }
         };
         auto commit_inputs_b = [&](int s) {
+            // one lane converts one staged 16-byte chunk (two inputs of one frame): a frame-table read, one 16-byte
+            // read each of the scale table and the staging slot, one 4-byte store -- straight-line, no loop
             const bool row_ok = s + p.in_row_off < p.T_in;     // (an out-of-range DMA leaves its slot undefined)
+            const int lk2 = lkin - 1;                          // log2 of the pairs per frame (kin_p / 2)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                       // opaque: the addresses below are derived per step, not kept
 #pragma unroll
             for (int ti = 0; ti < IN_TILES; ++ti) {
                 const int c = in_c0 + ti;
-                for (int e = lane; e < 16 * kin_p; e += 64) {
-                    const int f = e >> lkin, ci = e & (kin_p - 1);
-                    float v = 0.f;
-                    if (tab_fr[c * 16 + f] >= 0 && ci < n_in) {
-                        const float2 ss = tab_in[c * kin_p + ci];
-                        const int ch = (f << lcpf) + (ci >> 1);                      // chunk of this element
-                        const double* src = reinterpret_cast<const double*>(
-                            in_slots + (size_t)(c * 2 + (ch >> 6)) * 1024 + (size_t)(ch & 63) * 16) + (ci & 1);
-                        const double raw = row_ok ? *src : 0.0;
-                        v = fmaf((float)raw, ss.x, ss.y);
-                    }
-                    TR::store1(zt + (size_t)(c * 16 + f) * row_bytes + (size_t)(g.kin + ci) * ES, v);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {                  // 8 kin_p <= 128 pairs per 16-frame tile
+                    const int e2 = ln + 64 * k;
+                    const int f = (e2 >> lk2) & 15, c2 = e2 & ((kin_p >> 1) - 1), ci = 2 * c2;
+                    const bool live = tab_fr[c * 16 + f] >= 0 && ci < n_in;          // (n_in is even: whole pairs)
+                    const float4 ss = *reinterpret_cast<const float4*>(tab_in + c * kin_p + ci);
+                    const int ch = (f << lcpf) + c2;                                  // < 128 for every lane
+                    const double2 raw = *reinterpret_cast<const double2*>(
+                        in_slots + (size_t)(c * 2 + (ch >> 6)) * 1024 + (size_t)(ch & 63) * 16);
+                    const float v0 = live ? fmaf((float)(row_ok ? raw.x : 0.0), ss.x, ss.y) : 0.f;
+                    const float v1 = live ? fmaf((float)(row_ok ? raw.y : 0.0), ss.z, ss.w) : 0.f;
+                    if (e2 < 8 * kin_p)
+                        TR::store2(zt + (size_t)(c * 16 + f) * row_bytes + (size_t)(g.kin + ci) * ES, v0, v1);
+                    __builtin_amdgcn_sched_barrier(0);         // one chunk at a time: the registers are not there for four
                 }
             }
         };
