@@ -175,17 +175,18 @@ def run_config(torch, dist, params, *, precision, fit_precision, reservoirs, n_r
     nb = torch.zeros(G, dtype=torch.int64, device=sweep.device)
     T = params.t_frame + params.delay
     y_out = torch.empty((G * F, params.n_sub, sweep.n_out), dtype=torch.float64, device=sweep.device)
-    sweep.train(data["pilot_y"], data["pilot_x"], seed=1)      # W_out exists for predict-only mode
+    off = rank * G                  # global index of this rank's first block: noise and weight sets follow it
+    sweep.train(data["pilot_y"], data["pilot_x"], seed=1, group_offset=off)      # W_out exists for predict-only mode
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
     def step(i, timed):
         if not predict_only:
-            sweep.train(data["pilot_y"], data["pilot_x"], seed=i)
+            sweep.train(data["pilot_y"], data["pilot_x"], seed=i, group_offset=off)
         U = torch.view_as_real(data["data_y"]).reshape(G * F, params.t_frame, sweep.n_in)
         if timed:
             ev[i][0].record()
         y = sweep.bank.predict(U, F, T=T, transient=params.delay + params.cp, precision=precision,
-                               noise_mode="counter", seed=i, out=y_out)
+                               noise_mode="counter", seed=i, out=y_out, group_offset=off)
         if timed:
             ev[i][1].record()
         sweep.bank.detect_count(y, data["data_bits"], sweep.p_i, F, params.n_sub, params.n_t, params.m,

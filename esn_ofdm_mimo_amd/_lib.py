@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("ESN_HIP_LIB") or os.path.join(_PKG, "libesn_hip.so") 
 F64, F32, F16, BF16 = 0, 1, 2, 3
 PRECISIONS = {"f64": F64, "f32": F32, "f16": F16, "bf16": BF16}
 NOISE_NONE, NOISE_TENSOR, NOISE_COUNTER = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Shape(C.Structure):
@@ -35,12 +35,12 @@ SIGNATURES = {
     "esn_pack_readout": (C.c_int, [C.c_int, C.POINTER(Shape), C.c_int, _dp, _vp, _vp]),
     "esn_predict_batch": (C.c_int, [C.c_int, C.POINTER(Shape), _vp, _vp, _dp, _dp, _dp, _dp, _dp,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
-                                    C.c_double, C.c_int, _dp, C.c_uint64, _dp, _vp, C.c_size_t, _vp]),
+                                    C.c_double, C.c_int, _dp, C.c_uint64, C.c_uint64, _dp, _vp, C.c_size_t, _vp]),
     "esn_predict_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(Shape), C.c_int, C.c_int]),
     "esn_harvest_batch": (C.c_int, [C.c_int, C.POINTER(Shape), _vp, _dp, _dp, _dp, _dp, _dp, _dp,
-                                    C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, _dp, _vp]),
+                                    C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, C.c_uint64, _dp, _vp]),
     "esn_harvest_batch_f32": (C.c_int, [C.c_int, C.POINTER(Shape), _vp, _dp, _dp, _dp, _dp, _dp, _dp,
-                                        C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, _vp, _vp]),
+                                        C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, C.c_uint64, _vp, _vp]),
     "esn_readout_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "esn_readout_solve_batch": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           _dp, _dp, _dp, _ip, _vp, _vp]),
@@ -56,6 +56,9 @@ SIGNATURES = {
                                        C.c_double, _vp, _dp, _dp, _vp]),
     "esn_mmse_detect_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
                                         C.c_double, _dp, _dp, _vp, _vp, _vp, _dp, _vp]),
+    "esn_zf_detect_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
+                                      _dp, _dp, _vp, _vp, _vp, _dp, _vp]),
+    "esn_taps_to_freq": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _vp]),
     "esn_ldpc_encode": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "esn_qam_llr": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _vp]),
     "esn_ldpc_decode_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _dp,

@@ -115,8 +115,13 @@ class ReservoirBank:
         return self._packed_wout[precision]
 
     # ------------------------------------------------------------------ fit
-    def harvest(self, U, D, precision="f64", noise_mode="counter", noise_u=None, seed=0, e_dtype="f64"):
+    def harvest(self, U, D, precision="f64", noise_mode="counter", noise_u=None, seed=0, e_dtype="f64",
+                group_offset=0):
         """U [G,T,n_in], D [G,T,n_out] -> extended states E [G,T,n_res+n_in] (device).
+
+        group_offset: global index of group 0 in the caller's sweep -- the counter noise and (with several
+        weight sets) the weight set follow the GLOBAL group, so a sweep cut into chunks or ranks gives the
+        same states (include/esn_hip.h).
 
         e_dtype "f32" (MFMA precisions only) stores E as float32 -- exact for the state columns, 6e-8
         relative on the scaled inputs -- which halves the store tail here and the reads of `solve`."""
@@ -137,9 +142,13 @@ class ReservoirBank:
                             dtype=torch.float32 if f32 else torch.float64, device=self.device)
             check(fn(PRECISIONS[precision], C.byref(self.shape), ptr(self.packed_weights(precision)),
                      ptr(self.in_scale), ptr(self.in_shift), ptr(self.t_scale), ptr(self.t_shift),
-                     ptr(U), ptr(D), g, t, self.noise, nm, ptr(nz), int(seed) & (2**64 - 1), ptr(E),
-                     _lib.stream_handle()), "esn_harvest_batch")
+                     ptr(U), ptr(D), g, t, self.noise, nm, ptr(nz), int(seed) & (2**64 - 1), int(group_offset),
+                     ptr(E), _lib.stream_handle()), "esn_harvest_batch")
         return E
+
+    def chol_fits(self, rows, cols):
+        """Shapes the LDS-resident Cholesky solve covers (esn_readout_solve_chol_batch)."""
+        return min(rows, cols) <= 128 and self.n_outputs <= 8
 
     def solve(self, E, D, transient, method="qr"):
         """W_out[g] = (pinv(E[g][transient:]) @ scale(D[g][transient:])).T ; returns (W_out, status).
@@ -154,7 +163,7 @@ class ReservoirBank:
         D = _as_dev(D, torch, self.device)
         g, t, cols = E.shape
         rows = t - transient
-        fits = min(rows, cols) <= 128 and self.n_outputs <= 8
+        fits = self.chol_fits(rows, cols)
         if method == "auto":
             method = "chol" if fits else "qr"
         if e32 and method != "chol":
@@ -201,8 +210,8 @@ class ReservoirBank:
         return nbad
 
     def fit(self, U, D, transient=0, precision="f64", noise_mode="counter", noise_u=None, seed=0,
-            method="qr", e_dtype="f64"):
-        E = self.harvest(U, D, precision, noise_mode, noise_u, seed, e_dtype=e_dtype)
+            method="qr", e_dtype="f64", group_offset=0):
+        E = self.harvest(U, D, precision, noise_mode, noise_u, seed, e_dtype=e_dtype, group_offset=group_offset)
         W_out, status = self.solve(E, D, transient, method=method)
         self.set_readout(W_out)
         self.fit_status = status
@@ -210,8 +219,9 @@ class ReservoirBank:
 
     # ------------------------------------------------------------------ predict
     def predict(self, U, frames_per_group, T=None, transient=0, precision="f32", x0=None, y0=None,
-                noise_mode="counter", noise_u=None, seed=0, out=None):
-        """U [B,T_in,n_in] (frames ordered by group) -> Y [B,T-transient,n_out] (device, unscaled)."""
+                noise_mode="counter", noise_u=None, seed=0, out=None, group_offset=0):
+        """U [B,T_in,n_in] (frames ordered by group) -> Y [B,T-transient,n_out] (device, unscaled).
+        group_offset: global index of group 0 (noise key and weight set follow the global group)."""
         torch = self.torch
         U = _as_dev(U, torch, self.device)
         b, t_in = U.shape[0], U.shape[1]
@@ -243,7 +253,7 @@ class ReservoirBank:
                 ptr(self.packed_readout(precision)), ptr(self.in_scale), ptr(self.in_shift),
                 ptr(self.t_scale), ptr(self.t_shift), ptr(U), b, int(frames_per_group), t_in, T,
                 int(transient), ptr(x0), ptr(y0), self.noise, nm, ptr(nz), int(seed) & (2**64 - 1),
-                ptr(out), ptr(ws), wbytes, _lib.stream_handle()), "esn_predict_batch")
+                int(group_offset), ptr(out), ptr(ws), wbytes, _lib.stream_handle()), "esn_predict_batch")
         return out
 
     # ------------------------------------------------------------------ detector tail

@@ -7,9 +7,12 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libesn_hip.so")
-SOURCES = ["esn_api.hip", "esn_pack.hip", "esn_recur_f64.hip", "esn_recur_f64_mfma.hip", "esn_recur_mfma.hip", "esn_recur_big.hip", "esn_recur_rs.hip", "esn_recur_mfma_f32.hip", "esn_recur_mfma_f16.hip",
-           "esn_recur_mfma_bf16.hip",
+SOURCES = ["esn_api.hip", "esn_pack.hip", "esn_recur_f64.hip", "esn_recur_f64_mfma.hip", "esn_recur_mfma.hip",
+           "esn_recur_big.hip", "esn_recur_mfma_f32.hip", "esn_recur_mfma_f16.hip", "esn_recur_mfma_bf16.hip",
            "esn_solve.hip", "esn_detect.hip", "esn_gen.hip", "esn_baseline.hip", "esn_coded.hip"]
+# the register-resident-state predict kernel is a kept negative result: it is compiled only into
+# experiment builds (`ESN_WITH_RS=1 python esn_ofdm_mimo_amd/build.py --variant rs`), never into the product library
+WITH_RS = os.environ.get("ESN_WITH_RS") == "1"
 # -fno-slp-vectorize: SLP turns adjacent float32 adds/fmas into v_pk_*_f32, which issue far slower
 # than two scalar ops beside MFMAs (measured: predict kernel 13.97 -> 13.42 ms)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
@@ -42,7 +45,10 @@ def _build(LIB, bdir, extra, verbose):
     objs = []
     procs = []
     os.makedirs(os.path.join(PKG, bdir), exist_ok=True)
-    for src in SOURCES:
+    sources = SOURCES + (["esn_recur_rs.hip"] if WITH_RS and LIB.endswith("_rs.so") else [])
+    if len(sources) > len(SOURCES):
+        extra = list(extra) + ["-DESN_WITH_RS"]
+    for src in sources:
         obj = os.path.join(PKG, bdir, src.replace(".hip", ".o"))
         objs.append(obj)
         per_file = os.environ.get("ESN_FLAGS_" + src.replace(".hip", "").upper(), "").split()

@@ -15,9 +15,11 @@ size_t recur_f64_lds_bytes(int FB, int n_res, int n_in, int n_out);
 // esn_recur_f64_mfma.hip
 bool f64_mfma_geometry(int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_f64_mfma(const RecurParams& p, hipStream_t stream);
-// esn_recur_rs.hip
+#ifdef ESN_WITH_RS
+// esn_recur_rs.hip (a kept negative result, DESIGN.md 3.1b: only in builds made with ESN_WITH_RS=1)
 bool rs_path_applies(int precision, const RecurParams& p);
 int launch_recur_rs(int precision, const RecurParams& p, size_t wo_rs_off, hipStream_t stream);
+#endif
 // esn_recur_big.hip
 bool big_path_applies(int precision, const RecurParams& p);
 int big_slots(const RecurParams& p);
@@ -50,6 +52,7 @@ int launch_gen_frames(const FrameGenParams& fp, hipStream_t stream);
 // esn_baseline.hip
 int launch_channel_estimate(const ChanEstParams& cp, hipStream_t stream);
 int launch_mmse_detect(const MmseParams& mp, hipStream_t stream);
+int launch_taps_to_freq(const TapsFreqParams& tp, hipStream_t stream);
 // esn_coded.hip
 int launch_ldpc_encode(const LdpcEncodeParams& ep, hipStream_t stream);
 int launch_qam_llr(const LlrParams& lp, hipStream_t stream);
@@ -140,7 +143,7 @@ extern "C" {
 
 const char* esn_last_error(void) { return g_err; }
 
-int esn_abi_version(void) { return 6; }
+int esn_abi_version(void) { return 7; }
 
 int esn_debug_set(const char* key, const char* value) {
     if (!key) return fail(-1, "esn_debug_set: null key");
@@ -150,7 +153,14 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "mfma_geom_f32")) { parse3(value, k.geom32); return 0; }
     if (!strcmp(key, "chol_skip")) { k.chol_skip = value ? atoi(value) : 0; return 0; }
     if (!strcmp(key, "f64_mfma")) { k.f64_mfma = (value && value[0] == '0') ? 0 : 1; return 0; }
-    if (!strcmp(key, "rs")) { k.rs = (value && value[0] == '1') ? 1 : 0; return 0; }
+    if (!strcmp(key, "rs")) {
+#ifdef ESN_WITH_RS
+        k.rs = (value && value[0] == '1') ? 1 : 0; return 0;
+#else
+        if (value && value[0] == '1') return fail(-3, "esn_debug_set: the register-state kernel is not in this build (ESN_WITH_RS=1)");
+        return 0;
+#endif
+    }
     if (!strcmp(key, "big_gemm")) { k.big_gemm = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }
@@ -244,8 +254,8 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
                       const double* in_scale, const double* in_shift, const double* t_scale,
                       const double* t_shift, const double* U, int n_frames, int frames_per_group, int T_in,
                       int T, int transient, const double* x0, const double* y0, double noise, int noise_mode,
-                      const double* noise_u, uint64_t seed, double* Y, void* workspace, size_t workspace_bytes,
-                      void* stream) {
+                      const double* noise_u, uint64_t seed, uint64_t group_offset, double* Y, void* workspace,
+                      size_t workspace_bytes, void* stream) {
     RecurParams p;
     int rc = fill_common(p, precision, shape, "esn_predict_batch");
     if (rc) return rc;
@@ -280,6 +290,9 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
     p.U = U; p.x0 = x0; p.y0 = y0; p.noise_u = noise_u;
     p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
+    p.frame_off = (uint32_t)(group_offset * (uint64_t)frames_per_group);
+    p.wset_rot = (int)(group_offset % (uint64_t)p.n_wsets);
+    if (((uintptr_t)Y & 15) != 0) return fail(-1, "esn_predict_batch: Y must be 16-byte aligned");
     p.Y = Y;
     ESN_SET_STAMPS(p);
     // large reservoirs: one GEMM launch per step when the caller lends a workspace (else the persistent kernel)
@@ -293,10 +306,13 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
                                          (hipStream_t)stream), "esn_predict_batch");
     }
     // N_res 257..512, fp16/bf16: state in registers, one wave per SIMD (tiles of 128 slots like the skewed kernel)
+#ifdef ESN_WITH_RS
     if (knobs().rs && rs_path_applies(precision, p) &&
-        (size_t)n_frames * (T - transient) * p.n_out * 8 < 0x7fffffffu)
+        (size_t)n_frames * (T - transient) * p.n_out * 8 < 0x7fffffffu &&
+        (size_t)p.n_groups * p.wout_stride < 0x7fffffffu)         // its buffer descriptors are 31-bit
         return hip_fail(launch_recur_rs(precision, p, wout_big_offset(precision, p.n_out, p.g), (hipStream_t)stream),
                         "esn_predict_batch");
+#endif
     int e = m64 ? launch_recur_f64_mfma(p, (hipStream_t)stream)
             : (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
                                      : launch_recur_mfma(precision, p, (hipStream_t)stream);
@@ -316,7 +332,7 @@ size_t esn_predict_workspace_bytes(int precision, const esn_shape_t* shape, int 
 static int harvest_common(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
                       const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
                       const double* D, int n_groups, int T, double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, double* E, float* E32, void* stream) {
+                      uint64_t seed, uint64_t group_offset, double* E, float* E32, void* stream) {
     RecurParams p;
     int rc = fill_common(p, precision, shape, "esn_harvest_batch", true);
     if (rc) return rc;
@@ -347,6 +363,9 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     p.in_scale = in_scale; p.in_shift = in_shift; p.t_scale = t_scale; p.t_shift = t_shift;
     p.U = U; p.D = D; p.noise_u = noise_u;
     p.noise = noise; p.noise_mode = (noise == 0.0) ? ESN_NOISE_NONE : noise_mode; p.seed = seed;
+    p.frame_off = (uint32_t)group_offset;
+    p.wset_rot = (int)(group_offset % (uint64_t)p.n_wsets);
+    if ((((uintptr_t)E) | ((uintptr_t)E32)) & 15) return fail(-1, "esn_harvest_batch: E must be 16-byte aligned");
     p.E = E; p.E32 = E32;
     ESN_SET_STAMPS(p);
     int e = m64 ? launch_recur_f64_mfma(p, (hipStream_t)stream)
@@ -358,19 +377,19 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
 int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
                       const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
                       const double* D, int n_groups, int T, double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, double* E, void* stream) {
+                      uint64_t seed, uint64_t group_offset, double* E, void* stream) {
     if (!E) return fail(-1, "esn_harvest_batch: null pointer");
     return harvest_common(precision, shape, packed_w, in_scale, in_shift, t_scale, t_shift, U, D, n_groups, T, noise,
-                          noise_mode, noise_u, seed, E, nullptr, stream);
+                          noise_mode, noise_u, seed, group_offset, E, nullptr, stream);
 }
 
 int esn_harvest_batch_f32(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
                           const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
                           const double* D, int n_groups, int T, double noise, int noise_mode,
-                          const double* noise_u, uint64_t seed, float* E, void* stream) {
+                          const double* noise_u, uint64_t seed, uint64_t group_offset, float* E, void* stream) {
     if (!E) return fail(-1, "esn_harvest_batch_f32: null pointer");
     return harvest_common(precision, shape, packed_w, in_scale, in_shift, t_scale, t_shift, U, D, n_groups, T, noise,
-                          noise_mode, noise_u, seed, nullptr, E, stream);
+                          noise_mode, noise_u, seed, group_offset, nullptr, E, stream);
 }
 
 size_t esn_readout_solve_workspace_bytes(int n_groups, int rows, int cols, int n_out) {
@@ -507,24 +526,48 @@ int esn_channel_estimate(int n_blocks, int n_sub, int cp, int n_t, int n_r, int 
     return hip_fail(launch_channel_estimate(c, (hipStream_t)stream), "esn_channel_estimate");
 }
 
+static int linear_detect(const char* who, int zf, int n_frames, int frames_per_group, int n_sub, int cp, int n_t, int n_r,
+                         int bits_per_sym, const double* p_i, double no, const double* H, const double* y_cp,
+                         const uint8_t* tx_bits, long long* err_count, long long* bit_count, double* X_hat,
+                         void* stream) {
+    if (!p_i || !H || !y_cp || !tx_bits || !err_count || !bit_count)
+        return fail(-1, "%s: null pointer", who);
+    const int l2 = pow2_log(n_sub);
+    if (l2 < 1 || n_sub > 2048) return fail(-1, "%s: N=%d must be a power of two in [2, 2048]", who, n_sub);
+    if (n_frames <= 0 || frames_per_group <= 0 || cp < 0 || cp >= n_sub || n_t <= 0 || n_r <= 0 ||
+        bits_per_sym < 2 || (bits_per_sym & 1))
+        return fail(-1, "%s: invalid sizes", who);
+    MmseParams m;
+    m.n_frames = n_frames; m.frames_per_group = frames_per_group; m.n_sub = n_sub; m.log2n = l2; m.cp = cp;
+    m.n_t = n_t; m.n_r = n_r; m.m = bits_per_sym; m.zf = zf; m.p_i = p_i; m.no = no; m.H = H; m.y_cp = y_cp;
+    m.tx_bits = tx_bits; m.err = err_count; m.bits = bit_count; m.X_hat = X_hat;
+    int e = launch_mmse_detect(m, (hipStream_t)stream);
+    if (e == -1) return fail(-2, "%s: needs n_t <= 4 and n_r * N * 16 bytes of LDS", who);
+    return hip_fail(e, who);
+}
+
 int esn_mmse_detect_count(int n_frames, int frames_per_group, int n_sub, int cp, int n_t, int n_r, int bits_per_sym,
                           const double* p_i, double no, const double* H, const double* y_cp,
                           const uint8_t* tx_bits, long long* err_count, long long* bit_count, double* X_hat,
                           void* stream) {
-    if (!p_i || !H || !y_cp || !tx_bits || !err_count || !bit_count)
-        return fail(-1, "esn_mmse_detect_count: null pointer");
-    const int l2 = pow2_log(n_sub);
-    if (l2 < 1 || n_sub > 2048) return fail(-1, "esn_mmse_detect_count: N=%d must be a power of two in [2, 2048]", n_sub);
-    if (n_frames <= 0 || frames_per_group <= 0 || cp < 0 || cp >= n_sub || n_t <= 0 || n_r <= 0 ||
-        bits_per_sym < 2 || (bits_per_sym & 1))
-        return fail(-1, "esn_mmse_detect_count: invalid sizes");
-    MmseParams m;
-    m.n_frames = n_frames; m.frames_per_group = frames_per_group; m.n_sub = n_sub; m.log2n = l2; m.cp = cp;
-    m.n_t = n_t; m.n_r = n_r; m.m = bits_per_sym; m.p_i = p_i; m.no = no; m.H = H; m.y_cp = y_cp;
-    m.tx_bits = tx_bits; m.err = err_count; m.bits = bit_count; m.X_hat = X_hat;
-    int e = launch_mmse_detect(m, (hipStream_t)stream);
-    if (e == -1) return fail(-2, "esn_mmse_detect_count: needs n_t <= 4 and n_r * N * 16 bytes of LDS");
-    return hip_fail(e, "esn_mmse_detect_count");
+    return linear_detect("esn_mmse_detect_count", 0, n_frames, frames_per_group, n_sub, cp, n_t, n_r, bits_per_sym, p_i,
+                         no, H, y_cp, tx_bits, err_count, bit_count, X_hat, stream);
+}
+
+int esn_zf_detect_count(int n_frames, int frames_per_group, int n_sub, int cp, int n_t, int n_r, int bits_per_sym,
+                        const double* p_i, const double* H, const double* y_cp, const uint8_t* tx_bits,
+                        long long* err_count, long long* bit_count, double* X_hat, void* stream) {
+    return linear_detect("esn_zf_detect_count", 1, n_frames, frames_per_group, n_sub, cp, n_t, n_r, bits_per_sym, p_i,
+                         0.0, H, y_cp, tx_bits, err_count, bit_count, X_hat, stream);
+}
+
+int esn_taps_to_freq(int n_blocks, int n_sub, int n_t, int n_r, int isi, const double* taps, double* H, void* stream) {
+    if (!taps || !H) return fail(-1, "esn_taps_to_freq: null pointer");
+    if (n_blocks <= 0 || n_sub <= 0 || n_t <= 0 || n_r <= 0 || isi <= 0 || isi > n_sub)
+        return fail(-1, "esn_taps_to_freq: invalid sizes");
+    TapsFreqParams tp;
+    tp.n_blocks = n_blocks; tp.n_sub = n_sub; tp.n_t = n_t; tp.n_r = n_r; tp.isi = isi; tp.taps = taps; tp.H = H;
+    return hip_fail(launch_taps_to_freq(tp, (hipStream_t)stream), "esn_taps_to_freq");
 }
 
 int esn_ldpc_encode(int n_frames, int n_t, int k, int n, const uint8_t* P, const uint8_t* u, uint8_t* bits,

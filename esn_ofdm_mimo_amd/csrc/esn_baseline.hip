@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void mmse_detect_kernel(MmseParams mp) {
     }
     __syncthreads();
     fft_lds(Y, n_r, N, mp.log2n, -1.0);
-    const double p_i = mp.p_i[blk], lam = mp.no / p_i, isp = 1.0 / sqrt(p_i);
+    const double p_i = mp.p_i[blk], lam = mp.zf ? 1e-12 : mp.no / p_i, isp = 1.0 / sqrt(p_i);
     const int side = 1 << (m / 2);
     const double norm = sqrt(2.0 * (double)(side * side - 1) / 3.0);
     int errs = 0;
@@ -226,6 +226,32 @@ __global__ __launch_bounds__(256) void mmse_detect_kernel(MmseParams mp) {
         atomicAdd(reinterpret_cast<unsigned long long*>(mp.err + blk), (unsigned long long)e);
         atomicAdd(reinterpret_cast<unsigned long long*>(mp.bits + blk), (unsigned long long)(N * m * n_t));
     }
+}
+
+// Perfect-CSI channel: H[k] = sum_j c[j] e^{-2 pi i jk/N} per link (H_true of OFDM_MIMO_2-2_NBF_LDPC.py:273-279)
+__global__ __launch_bounds__(256) void taps_to_freq_kernel(TapsFreqParams tp) {
+    const int N = tp.n_sub, n_t = tp.n_t, n_r = tp.n_r, isi = tp.isi;
+    const size_t total = (size_t)tp.n_blocks * N * n_r * n_t;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int tx = (int)(e % n_t), rx = (int)((e / n_t) % n_r), k = (int)((e / ((size_t)n_t * n_r)) % N);
+        const size_t blk = e / ((size_t)n_t * n_r * N);
+        const double* c = tp.taps + (((blk * n_r + rx) * n_t + tx) * isi) * 2;
+        double hr = 0.0, hi = 0.0;
+        for (int j = 0; j < isi; ++j) {
+            double sn, cs;
+            sincospi(-2.0 * (double)((j * k) % N) / (double)N, &sn, &cs);
+            hr += c[2 * j] * cs - c[2 * j + 1] * sn;
+            hi += c[2 * j] * sn + c[2 * j + 1] * cs;
+        }
+        tp.H[2 * e] = hr; tp.H[2 * e + 1] = hi;
+    }
+}
+
+int launch_taps_to_freq(const TapsFreqParams& tp, hipStream_t stream) {
+    const size_t total = (size_t)tp.n_blocks * tp.n_sub * tp.n_r * tp.n_t;
+    const int blocks = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+    hipLaunchKernelGGL(taps_to_freq_kernel, dim3(blocks), dim3(256), 0, stream, tp);
+    return (int)hipGetLastError();
 }
 
 int launch_channel_estimate(const ChanEstParams& cp, hipStream_t stream) {

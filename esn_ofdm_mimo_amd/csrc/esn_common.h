@@ -61,6 +61,9 @@ struct RecurParams {
     const double* x0; const double* y0;
     const double* noise_u;
     double noise; int noise_mode; uint64_t seed;
+    uint32_t frame_off;    // counter noise: global index of this launch's frame 0 (= group_offset * F, mod 2^32), so a
+                           // frame draws the same noise whichever launch, chunk or rank it lands in
+    int wset_rot;          // n_wsets > 1: group g uses weight set (g + wset_rot) % n_wsets (= group_offset % n_wsets)
     double* Y; double* E;
     float* E32;            // harvest: when set, the extended states are stored as float32 here (E unused)
     unsigned long long* stamps;   // diagnostic build (-DESN_STAMPS) only: [block0 wave][8] cycle sums
@@ -109,8 +112,14 @@ struct ChanEstParams {
     const double* y_ls_cp;       // complex [G][T][n_r]
     double* H;                   // complex [G][N][n_r][n_t]
 };
+struct TapsFreqParams {
+    int n_blocks, n_sub, n_t, n_r, isi;
+    const double* taps;          // complex [G][n_r][n_t][isi]
+    double* H;                   // complex [G][N][n_r][n_t]
+};
 struct MmseParams {
     int n_frames, frames_per_group, n_sub, log2n, cp, n_t, n_r, m;
+    int zf;                      // 1: zero forcing, G = H^H H + 1e-12 I (driver :34-39); 0: MMSE, G = H^H H + No/Pi I
     const double* p_i; double no;
     const double* H;             // complex [G][N][n_r][n_t]
     const double* y_cp;          // complex [B][T][n_r]
@@ -159,7 +168,11 @@ __device__ __forceinline__ int slot_group(const RecurParams& p, int slot, int& j
 }
 __device__ __forceinline__ int slot_group(const RecurParams& p, int slot) { int j; return slot_group(p, slot, j); }
 // weight set of the tile that starts at slot0
-__device__ __forceinline__ int slot_wset(const RecurParams& p, int slot0) { return p.spw ? slot0 / p.spw : 0; }
+__device__ __forceinline__ int slot_wset(const RecurParams& p, int slot0) {
+    if (!p.spw) return 0;
+    const int w = slot0 / p.spw + p.wset_rot;
+    return w >= p.n_wsets ? w - p.n_wsets : w;
+}
 // slot -> frame index (or -1 for padding) and its group
 __device__ __forceinline__ int slot_frame(const RecurParams& p, int slot, int& grp) {
     int j;

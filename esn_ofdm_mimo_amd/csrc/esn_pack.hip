@@ -115,7 +115,8 @@ __host__ __device__ inline size_t packed_wout_persistent_bytes(int es, int n_out
     return (size_t)g.ro_parts * n_ot * 16 * g.Kp * es + 16;
 }
 size_t big_wout_image_bytes(int Mp);
-size_t rs_wout_image_bytes(int Kp);
+// (defined in esn_recur_rs.hip in ESN_WITH_RS=1 builds; g.rs is 0 otherwise, so this is never called)
+static inline size_t rs_wout_image_bytes(int Kp) { return (size_t)(Kp / 16) * 1024 + 16; }
 
 // Readout image for the 16x16 MFMA: [part][ot][64-byte k-group][lane][16 B] then a
 // 16-byte trailer {1/gain, gain, 0, 0} (float).  gain is a power of two that brings

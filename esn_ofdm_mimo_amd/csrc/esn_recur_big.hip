@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512) void big_step_kernel(BigParams bp) {
         const int g_lo = (ct_g * 32) / p.Fpad, g_hi = (ct_g * 32 + 16) / p.Fpad;       // wave-uniform
         uint32_t key = 0;
         const double* nz = nullptr;
-        if (NOISE == ESN_NOISE_COUNTER) key = noise_key(p.seed, (uint32_t)fr, (uint32_t)bp.step);
+        if (NOISE == ESN_NOISE_COUNTER) key = noise_key(p.seed, (uint32_t)fr + p.frame_off, (uint32_t)bp.step);
         if (NOISE == ESN_NOISE_TENSOR && fr >= 0) nz = p.noise_u + ((size_t)fr * p.S + bp.step) * n_res;
         f32x16 racc_lo, racc_hi;
 #pragma unroll

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
                         u0 = nz[r0];
                         if (has1) u1 = nz[r1];
                     } else {
-                        uint32_t key = noise_key(p.seed, fr, (uint32_t)s);
+                        uint32_t key = noise_key(p.seed, (uint32_t)fr + p.frame_off, (uint32_t)s);
                         u0 = noise_uniform(key, r0);
                         u1 = noise_uniform(key, r1);
                     }

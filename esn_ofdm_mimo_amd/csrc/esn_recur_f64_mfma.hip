@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512) void recur_f64_mfma_kernel(RecurParams p) {
                 const int fr = tab_fr[fcol];
                 uint32_t key = 0;
                 const double* nz = nullptr;
-                if (p.noise_mode == ESN_NOISE_COUNTER && fr >= 0) key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s);
+                if (p.noise_mode == ESN_NOISE_COUNTER && fr >= 0) key = noise_key(p.seed, (uint32_t)fr + p.frame_off, (uint32_t)s);
                 if (p.noise_mode == ESN_NOISE_TENSOR && fr >= 0) nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {

@@ -47,7 +47,11 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
     g->kfb = g->kin + round_up(n_in, 4);
     // (reservoirs beyond 1024: K padded to whole 64-deep chunks of the launch-per-step GEMM, esn_recur_big.hip)
     g->Kp = round_up(g->kfb + round_up(n_out, 4), (es == 2 && n_res > 1024) ? 64 : 32);
+#ifdef ESN_WITH_RS
     g->rs = (es == 2 && g->Mp == 512 && g->Kp == 544 && g->kfb - g->kin == 16 && n_out <= 8) ? 1 : 0;
+#else
+    g->rs = 0;      // the register-state kernel (and its read-out image) exist only in ESN_WITH_RS=1 builds
+#endif
     g->big = (es == 2 && n_res > 1024 && n_in <= 16 && n_out <= 8 && g->Mp % 256 == 0 && g->Mp <= 2048 &&
               g->kfb - g->kin + round_up(n_out, 4) <= 32) ? 1 : 0;
     // row stride: an odd number of 16-byte slots -> conflict-free b128 column reads

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                 uint32_t key = 0;
                 const double* nz = nullptr;
                 if (NOISE == ESN_NOISE_COUNTER)
-                    key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
+                    key = noise_key(p.seed, (uint32_t)fr + p.frame_off, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
                 if (NOISE == ESN_NOISE_TENSOR && fr >= 0)
                     nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
                 // (Tried: a packed-half odd Taylor series for tanh on small pre-activations -- 5 v_pk instructions per
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(NW * 64) void recur_mfma_kernel(RecurParams p) {
                 uint32_t key = 0;
                 const double* nz = nullptr;
                 if (NOISE == ESN_NOISE_COUNTER)
-                    key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
+                    key = noise_key(p.seed, (uint32_t)fr + p.frame_off, (uint32_t)s) + (uint32_t)(wave * MT * 8 + h) * 0x9E3779B9U;
                 if (NOISE == ESN_NOISE_TENSOR && fr >= 0)
                     nz = p.noise_u + ((size_t)fr * p.S + s) * n_res;
 #pragma unroll

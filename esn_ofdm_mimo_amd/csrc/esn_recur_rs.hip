@@ -44,7 +44,7 @@ constexpr int RS_GC = 3;                      // read-out chunks per step (group
 
 // per-group read-out image of this kernel: [NKG k-groups][64 lanes][16 B] (row = lane & 31: 0-7 hi, 8-15 lo,
 // 16-31 zero; k natural), then {1/gain, gain, 0, 0}
-size_t rs_wout_image_bytes(int Kp) { return (size_t)(Kp / 16) * 1024 + 16; }
+static inline size_t rs_wout_image_bytes(int Kp) { return (size_t)(Kp / 16) * 1024 + 16; }
 
 bool rs_path_applies(int precision, const RecurParams& p) {
     const int kin_p = p.g.kfb - p.g.kin;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void recur_rs_kernel(RecurParams p, size_t wo_
     for (int s = 0; s < p.S; ++s) {
         ESN_STAMP(t_s0)
         uint32_t key = 0;
-        if (NOISE == ESN_NOISE_COUNTER) key = noise_key(p.seed, (uint32_t)fr, (uint32_t)s);
+        if (NOISE == ESN_NOISE_COUNTER) key = noise_key(p.seed, (uint32_t)fr + p.frame_off, (uint32_t)s);
         f32x16 racc_lo, racc_hi;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { racc_lo[i] = 0.f; racc_hi[i] = 0.f; }

@@ -220,16 +220,23 @@ complex_as_io = _view_real
 
 
 def blocks_for_rank(rank, world_size, n_blocks):
-    """Round-robin deal of coherence blocks to ranks: the union over ranks is
-    range(n_blocks) and block b's random streams depend on b only, never on the rank."""
-    return list(range(rank, n_blocks, world_size))
+    """Contiguous deal of coherence blocks to ranks: rank r owns blocks
+    [r n / W, (r+1) n / W); the union over ranks is range(n_blocks).  A block's random streams, state
+    noise and (per-block reservoirs) weight set depend on its GLOBAL index only -- never on the rank,
+    the chunk or the launch it lands in -- so the summed counters are identical for any world size.
+    (Contiguous ranges, so that a chunk of a rank's blocks is one run of global indices and one
+    `group_offset` describes it to the kernels.)"""
+    lo = (rank * n_blocks) // world_size
+    hi = ((rank + 1) * n_blocks) // world_size
+    return list(range(lo, hi))
 
 
 def reduce_counters(counters, dist=None, world_size=1):
     """The path's only collective: one all_reduce(SUM) of the int64 [n_snr, 2] (errors, bits)
     tensor (RCCL over xGMI on GPUs, gloo on CPU).  Integer sums are order independent, so the
-    result is bit-identical for any world size."""
-    if dist is not None and world_size > 1:
+    result is bit-identical for any world size.  Runs whenever a process group is handed in (a
+    one-rank group included); `dist=None` is the single-process path."""
+    if dist is not None and (world_size > 1 or dist.is_initialized()):
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     return counters
 
@@ -248,12 +255,13 @@ class DetectorSweep:
 
     def __init__(self, params: LinkParams, n_reservoir=512, spectral_radius=0.9, sparsity=0.1, noise=0.001,
                  seed=0, precision="f32", fit_precision="f64", reservoirs="shared", pool=8, device=None,
-                 rank=0, world_size=1, solve_method="auto"):
+                 rank=0, world_size=1, solve_method="auto", train_ebno=None):
         torch = _lib.require_gpu()
         self.torch, self.p = torch, params
         self.rank, self.world = rank, world_size
         self.precision, self.fit_precision = precision, fit_precision
         self.solve_method = solve_method
+        self.train_ebno = train_ebno      # not None: every ESN is trained at this fixed Eb/No
         self.n_in, self.n_out, self.n_res = 2 * params.n_r, 2 * params.n_t, n_reservoir
         self.seed = seed
         self.src = FrameSource(params, device, seed)
@@ -273,8 +281,18 @@ class DetectorSweep:
         self.bank.set_scaling(ones_in * p.input_scaling(ebno_db), None, ones_out * p.teacher_scale, None)
         self.p_i = torch.full((n_groups,), p.p_i(ebno_db), dtype=torch.float64, device=self.device)
 
-    def train(self, pilot_y, pilot_x, seed=0):
-        """helper_mimo_esn_generic.py:58-86 for G blocks: delay d, nForget = d + CP, one harvest + solve."""
+    def stream_seed(self, snr_idx, leg):
+        """64-bit seed of the state-noise stream of one Eb/No point; leg 0 = training (harvest), 1 = detection.
+        With the kernels' global frame index this makes the noise a function of (seed, snr, leg, global frame,
+        step, row) -- independent of chunking and world size."""
+        h = (int(self.seed) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) % (2 ** 64)
+        for k in (snr_idx, leg):
+            h = ((h ^ (h >> 31)) * 0xBF58476D1CE4E5B9 + int(k) + 1) % (2 ** 64)
+        return h
+
+    def train(self, pilot_y, pilot_x, seed=0, group_offset=0):
+        """helper_mimo_esn_generic.py:58-86 for G blocks: delay d, nForget = d + CP, one harvest + solve.
+        group_offset = global index of the first block (noise key and weight set follow the global block)."""
         torch, p = self.torch, self.p
         d = p.delay
         g, t = pilot_y.shape[0], pilot_y.shape[1]
@@ -286,11 +304,10 @@ class DetectorSweep:
         # float32 extended states on the all-GPU fast path (fp16/bf16 harvest + Cholesky): the state
         # columns are exactly representable, the fit is unchanged to ~1e-7
         rows, cols = t + d - p.forget, self.bank.n_reservoir + self.n_in
-        chol = self.solve_method == "chol" or (self.solve_method == "auto" and min(rows, cols) <= 128
-                                               and self.n_out <= 8)
+        chol = self.solve_method == "chol" or (self.solve_method == "auto" and self.bank.chol_fits(rows, cols))
         e_dtype = "f32" if (chol and self.fit_precision in ("f16", "bf16")) else "f64"
         E = self.bank.fit(U, D, transient=p.forget, precision=self.fit_precision, noise_mode="counter",
-                          seed=seed, method=self.solve_method, e_dtype=e_dtype)
+                          seed=seed, method=self.solve_method, e_dtype=e_dtype, group_offset=group_offset)
         self._cont = None
         if p.continuation:      # laststate / lastoutput of pyESN.py:195-197: training-final state, scaled teacher
             y_last = D[:, -1, :]
@@ -310,37 +327,73 @@ class DetectorSweep:
             self.bank.set_readout(self.bank.W_out)
         return n
 
-    def detect(self, data_y, data_bits, frames_per_block, err, bits, seed=0, out=None):
+    def detect(self, data_y, data_bits, frames_per_block, err, bits, seed=0, out=None, group_offset=0):
         """driver:433-456 for all data frames of G blocks: predict (d trailing zero rows synthesised
         in-kernel) -> fused FFT/slicer/count."""
         p = self.p
         U = _view_real(data_y)
         x0, y0 = self._cont if (p.continuation and getattr(self, "_cont", None)) else (None, None)
         y = self.bank.predict(U, frames_per_block, T=p.t_frame + p.delay, transient=p.forget, x0=x0, y0=y0,
-                              precision=self.precision, noise_mode="counter", seed=seed, out=out)
+                              precision=self.precision, noise_mode="counter", seed=seed, out=out,
+                              group_offset=group_offset)
         self.bank.detect_count(y, data_bits, self.p_i, frames_per_block, p.n_sub, p.n_t, p.m, err=err, bits=bits)
         return y
 
-    def run(self, ebno_list, blocks_per_snr, frames_per_block=None, chunk_blocks=64, dist=None):
-        """Returns BER[n_snr] (identical on every rank).  Blocks are dealt round-robin to ranks."""
+    def default_chunk_blocks(self, frames_per_block):
+        """Blocks per launch that fill the chip with whole rounds of workgroup tiles: about five tiles per CU
+        (the benchmark's choice), i.e. 5 * CUs * tile_frames slots at ceil16(F) slots per block."""
+        info = _lib.device_info()
+        tile = self.bank.tile_frames(self.precision)
+        fpad = ((frames_per_block + 15) // 16) * 16
+        return max(1, (5 * info["cu_count"] * tile) // fpad)
+
+    def _chunk(self, ebno, si, ids, F, repair):
+        """One launch group: generate, train, detect the contiguous global blocks `ids`; returns the device
+        tensor [errors, bits, flagged fits] (int64) without synchronising the host unless `repair`."""
+        torch = self.torch
+        g = len(ids)
+        data = self.src.blocks_fast(ebno, si, ids[0], g, F)
+        self.set_snr(ebno, g)
+        if self.train_ebno is not None:
+            # the "train@fixed Eb/No" ESN of the block-fading drivers (OFDM_MIMO_2-2_NBF_LDPC.py:181-183,347-367):
+            # pilot generated at the training Eb/No over the SAME taps, input scaling of that Eb/No at train AND
+            # detect time, evaluated on the data frames of the actual Eb/No (:440-448)
+            _, px, py = self.src.frames(data["taps"], 1, self.train_ebno, si, ids[0], 0, want_x=True)
+            data["pilot_y"], data["pilot_x"] = py, px
+            ones_in = torch.ones((g, self.n_in), dtype=torch.float64, device=self.device)
+            self.bank.in_scale = ones_in * self.p.input_scaling(self.train_ebno)
+        E = self.train(data["pilot_y"], data["pilot_x"], seed=self.stream_seed(si, 0), group_offset=ids[0])
+        if repair:
+            self.repair_fit(E)
+        err = torch.zeros(g, dtype=torch.int64, device=self.device)
+        nb = torch.zeros(g, dtype=torch.int64, device=self.device)
+        self.detect(data["data_y"], data["data_bits"], F, err, nb, seed=self.stream_seed(si, 1), group_offset=ids[0])
+        flagged = self.bank.fit_status.ne(0).sum().to(torch.int64) if not repair else torch.zeros(
+            (), dtype=torch.int64, device=self.device)
+        return torch.stack([err.sum(), nb.sum(), flagged])
+
+    def run(self, ebno_list, blocks_per_snr, frames_per_block=None, chunk_blocks=None, dist=None):
+        """Returns (BER[n_snr], counters [n_snr, 2]) -- identical on every rank and for every world size and
+        chunking (contiguous block ranges per rank; every stream keyed by global indices).  No host
+        synchronisation inside an Eb/No point: the Cholesky status flags are summed on the device and read once
+        per point; a chunk with a flagged fit (none on any run so far) is redone with the QR repair."""
         torch = self.torch
         F = frames_per_block or self.p.coherence_symbols
+        chunk = int(chunk_blocks or self.default_chunk_blocks(F))
         n_snr = len(ebno_list)
         counters = torch.zeros((n_snr, 2), dtype=torch.int64, device=self.device)
+        mine = blocks_for_rank(self.rank, self.world, blocks_per_snr)
+        self.fits_repaired = 0
         for si, ebno in enumerate(ebno_list):
-            mine = blocks_for_rank(self.rank, self.world, blocks_per_snr)
-            for c0 in range(0, len(mine), chunk_blocks):
-                ids = mine[c0:c0 + chunk_blocks]
-                g = len(ids)
-                data = self.src.blocks(ebno, si, ids, F)
-                self.set_snr(ebno, g)
-                E = self.train(data["pilot_y"], data["pilot_x"], seed=self.seed + 1000 * si + ids[0])
-                self.repair_fit(E)
-                err = torch.zeros(g, dtype=torch.int64, device=self.device)
-                nb = torch.zeros(g, dtype=torch.int64, device=self.device)
-                self.detect(data["data_y"], data["data_bits"], F, err, nb, seed=self.seed + 1000 * si + ids[0])
-                counters[si, 0] += err.sum()
-                counters[si, 1] += nb.sum()
+            chunks = [mine[c0:c0 + chunk] for c0 in range(0, len(mine), chunk)]
+            if not chunks:
+                continue
+            res = torch.stack([self._chunk(ebno, si, ids, F, repair=False) for ids in chunks])   # [n_chunks, 3]
+            if int(res[:, 2].sum().item()):                     # the point's one host read
+                for ci in torch.nonzero(res[:, 2]).flatten().tolist():
+                    self.fits_repaired += int(res[ci, 2].item())
+                    res[ci] = self._chunk(ebno, si, chunks[ci], F, repair=True)
+            counters[si] += res[:, :2].sum(dim=0)
         reduce_counters(counters, dist, self.world)
         c = counters.cpu().numpy()
         return c[:, 0] / np.maximum(c[:, 1], 1), c
@@ -365,11 +418,11 @@ def coded_ber_point(sweep, code, ebno_db, snr_idx, n_blocks, frames_per_block=No
     _, _, dy = src.frames(taps, F, ebno_db, snr_idx, 0, 1, bits_in=tx_bits)
     # ESN
     sweep.set_snr(ebno_db, G)
-    E = sweep.train(py, px, seed=seed + snr_idx)
+    E = sweep.train(py, px, seed=sweep.stream_seed(snr_idx, 0) + seed)
     sweep.repair_fit(E)
     U = _view_real(dy)
     y = sweep.bank.predict(U, F, T=p.t_frame + p.delay, transient=p.forget, precision=sweep.precision,
-                           noise_mode="counter", seed=seed + snr_idx)
+                           noise_mode="counter", seed=sweep.stream_seed(snr_idx, 1) + seed)
     e_esn, n_esn, xh = sweep.bank.detect_count(y, tx_bits, sweep.p_i, F, p.n_sub, p.n_t, p.m, want_xhat=True)
     x_esn = torch.view_as_complex(xh.view(G * F, p.n_sub, p.n_t, 2).contiguous())
     # LS/MMSE baseline

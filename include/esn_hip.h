@@ -85,7 +85,8 @@ int esn_abi_version(void);
  *   "chol_skip"     bit mask of Cholesky-solve phases to drop (timing only, wrong results)
  *   "f64_mfma"      "0" = ESN_F64 batches on the vector-ALU kernel instead of the float64 matrix pipe
  *   "rs"            "1" = fp16/bf16 predict at N_res 257..512 on the register-resident-state kernel
- *                   (esn_recur_rs.hip; an experiment kept for A/B runs) instead of the skewed LDS-state kernel
+ *                   (esn_recur_rs.hip; an experiment kept for A/B runs, compiled only into ESN_WITH_RS=1 builds:
+ *                   the product library answers -3) instead of the skewed LDS-state kernel
  *   "big_gemm"      "0" = N_res > 1024 predict on the persistent kernel even when a workspace is given
  * Returns 0, or -1 for an unknown key. */
 int esn_debug_set(const char* key, const char* value);
@@ -120,7 +121,13 @@ int esn_pack_readout(int precision, const esn_shape_t* shape, int n_groups,
  *
  * Frames are ordered by group: frame b belongs to group b / frames_per_group
  * (its W_out, scalings, initial state) and, when shape->n_wsets > 1, to weight
- * set (b / frames_per_group) % n_wsets.
+ * set (group_offset + b / frames_per_group) % n_wsets.
+ *
+ *   group_offset  global index of this call's group 0 in the caller's sweep (0 for a stand-alone call).  The
+ *                 counter noise of frame b is keyed by (seed, group_offset * frames_per_group + b, step, row) and the
+ *                 weight set by the global group, so cutting a sweep into chunks, launches or ranks
+ *                 changes neither: a frame's result is a function of its global index only.  (The frame index
+ *                 enters the key modulo 2^32.)
  *
  *   packed_w      from esn_pack_weights            packed_wout  from esn_pack_readout
  *   in_scale/in_shift   [n_groups][n_in]  or NULL (=1 / =0)        (pyESN.py:131-134)
@@ -129,7 +136,7 @@ int esn_pack_readout(int precision, const esn_shape_t* shape, int n_groups,
  *   x0, y0        [n_groups][n_res], [n_groups][n_out] start state and fed-back
  *                 output (continuation=True: laststate/lastoutput, :234-237) or NULL (zeros)
  *   noise_u       [B][T][n_res] uniforms when noise_mode == ESN_NOISE_TENSOR
- *   Y             [B][T-transient][n_out], unscaled (:255)
+ *   Y             [B][T-transient][n_out], unscaled (:255); 16-byte aligned (rows are written as 16-byte pairs)
  *   workspace     device scratch of esn_predict_workspace_bytes(...) bytes, or NULL.  Only reservoirs
  *                 beyond 1024 units in fp16/bf16 use it (there the recurrence runs as one tiled GEMM launch
  *                 per timestep with the state images in the workspace); with NULL every shape runs on the
@@ -144,7 +151,8 @@ int esn_predict_batch(int precision, const esn_shape_t* shape,
                       int T_in, int T, int transient,
                       const double* x0, const double* y0,
                       double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, double* Y, void* workspace, size_t workspace_bytes, void* stream);
+                      uint64_t seed, uint64_t group_offset,
+                      double* Y, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Batched state harvest of ESN.fit: one training sequence per group.
  *
@@ -152,6 +160,8 @@ int esn_predict_batch(int precision, const esn_shape_t* shape,
  *   E [n_groups][T][n_res+n_in] = hstack(states, inputs_scaled) (:189); row 0 of
  *   the states is zero and input row 0 is never fed (:179-182).
  *   noise_u [n_groups][T-1][n_res] when noise_mode == ESN_NOISE_TENSOR.
+ *   group_offset: as in esn_predict_batch (noise key and weight set follow the GLOBAL group index);
+ *   E is 16-byte aligned.
  *   precision: ESN_F64 / ESN_F32 keep the states at (better than) float32; ESN_F16 / ESN_BF16
  *   harvest states rounded to the operand type (round-off ~6e-6 abs, far below the model's own
  *   state noise 2.9e-4 rms) -- statistically equivalent, not bit-comparable.
@@ -162,7 +172,7 @@ int esn_harvest_batch(int precision, const esn_shape_t* shape,
                       const double* t_scale, const double* t_shift,
                       const double* U, const double* D, int n_groups, int T,
                       double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, double* E, void* stream);
+                      uint64_t seed, uint64_t group_offset, double* E, void* stream);
 
 /* Same harvest, extended states stored as float32 (MFMA precisions only: their state columns are
  * exactly representable, the scaled-input columns round at 6e-8 relative).  Halves the harvest's
@@ -174,7 +184,7 @@ int esn_harvest_batch_f32(int precision, const esn_shape_t* shape,
                           const double* t_scale, const double* t_shift,
                           const double* U, const double* D, int n_groups, int T,
                           double noise, int noise_mode, const double* noise_u,
-                          uint64_t seed, float* E, void* stream);
+                          uint64_t seed, uint64_t group_offset, float* E, void* stream);
 
 /* W_out[g] = (pinv(E[g][transient:]) @ (D[g][transient:]*t_scale + t_shift)).T  (:191-192)
  *
@@ -249,7 +259,11 @@ int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_
  *                        (Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:358-382).
  * esn_mmse_detect_count  y_cp complex [B][T][n_r] -> X = (H^H H + No/Pi I)^-1 H^H Y / sqrt(Pi) per
  *                        subcarrier (:40-45, :444-448), hard decision + error count as in
- *                        esn_detect_count; n_t <= 4.  X_hat complex [B][N][n_t] optional. */
+ *                        esn_detect_count; n_t <= 4.  X_hat complex [B][N][n_t] optional.
+ * esn_zf_detect_count    the same with G = H^H H + 1e-12 I: equalize_zf (:34-39; OFDM_MIMO_2-2_NBF_LDPC.py:41-47),
+ *                        "LS-ZF" with an estimated H and "Perfect-ZF" with the true one (:450-460).
+ * esn_taps_to_freq       taps complex [G][n_r][n_t][isi] -> the true channel H complex [G][N][n_r][n_t]
+ *                        = FFT_N of the zero-padded impulse response (H_true, OFDM_MIMO_2-2_NBF_LDPC.py:273-279). */
 int esn_channel_estimate(int n_blocks, int n_sub, int cp, int n_t, int n_r, int isi, int bits_per_sym,
                          const double* p_i, double no, const uint8_t* pilot_bits,
                          const double* y_ls_cp, double* H, void* stream);
@@ -257,6 +271,11 @@ int esn_mmse_detect_count(int n_frames, int frames_per_group, int n_sub, int cp,
                           int bits_per_sym, const double* p_i, double no, const double* H,
                           const double* y_cp, const uint8_t* tx_bits,
                           long long* err_count, long long* bit_count, double* X_hat, void* stream);
+int esn_zf_detect_count(int n_frames, int frames_per_group, int n_sub, int cp, int n_t, int n_r,
+                        int bits_per_sym, const double* p_i, const double* H,
+                        const double* y_cp, const uint8_t* tx_bits,
+                        long long* err_count, long long* bit_count, double* X_hat, void* stream);
+int esn_taps_to_freq(int n_blocks, int n_sub, int n_t, int n_r, int isi, const double* taps, double* H, void* stream);
 
 /* ---- Coded leg of the north-star driver, float64.  The reference delegates the code
  * to the un-vendored package pyldpc (requirements-sm2.txt:5); these entry points restate its

@@ -89,11 +89,40 @@ def estimate_channel(cfg: LinkConfig, ebno_db, x_ls, y_ls_cp):
     return h
 
 
-def mmse_detect(cfg: LinkConfig, ebno_db, h, y_cp):
-    """X_hat [N, n_t] = (H^H H + No/Pi I)^-1 H^H Y / sqrt(Pi) per subcarrier (driver:40-45,444-448)."""
+def equalize_mmse(y_k, h_k, power_scale, noise_over_power):
+    """(H^H H + nop I)^-1 H^H y / power_scale for one subcarrier (driver:40-45)."""
+    hh = h_k.conj().T
+    g = hh @ h_k + noise_over_power * np.eye(h_k.shape[1], dtype=h_k.dtype)
+    return np.linalg.solve(g, hh @ y_k) / power_scale
+
+
+def equalize_zf(y_k, h_k, power_scale):
+    """(H^H H + 1e-12 I)^-1 H^H y / power_scale for one subcarrier (driver:34-39;
+    OFDM_MIMO_2-2_NBF_LDPC.py:41-47 -- Perfect-ZF with the true H, LS-ZF with the estimate, :450-460)."""
+    hh = h_k.conj().T
+    g = hh @ h_k + 1e-12 * np.eye(h_k.shape[1], dtype=h_k.dtype)
+    return np.linalg.solve(g, hh @ y_k) / power_scale
+
+
+def taps_to_freq(cfg: LinkConfig, taps):
+    """True channel H [N, n_r, n_t] = FFT_N of the zero-padded taps per link
+    (Perfect-CSI ZF, OFDM_MIMO_2-2_NBF_LDPC.py:281-285)."""
+    return np.transpose(np.fft.fft(taps, cfg.n_sub, axis=2), (2, 0, 1))
+
+
+def linear_detect(cfg: LinkConfig, ebno_db, h, y_cp, reg=None):
+    """X_hat [N, n_t]: per-subcarrier MMSE (reg = No/Pi, the default) or ZF (reg = 0 -> 1e-12)
+    of the received frame (driver:444-448; NBF driver:450-460)."""
     n, p_i = cfg.n_sub, cfg.p_i(ebno_db)
     y = (1.0 / n) * np.fft.fft(y_cp[cfg.cp:], axis=0)              # [N, n_r]
-    hh = np.conj(np.transpose(h, (0, 2, 1)))                        # [N, n_t, n_r]
-    g = hh @ h + (cfg.no / p_i) * np.eye(cfg.n_t)[None]
-    x = np.linalg.solve(g, hh @ y[:, :, None])[:, :, 0]
-    return x / math.sqrt(p_i)
+    reg = cfg.no / p_i if reg is None else reg
+    out = np.zeros((n, cfg.n_t), dtype=np.complex128)
+    for k in range(n):
+        out[k] = equalize_zf(y[k], h[k], math.sqrt(p_i)) if reg == 0 else \
+            equalize_mmse(y[k], h[k], math.sqrt(p_i), reg)
+    return out
+
+
+def mmse_detect(cfg: LinkConfig, ebno_db, h, y_cp):
+    """X_hat [N, n_t] = (H^H H + No/Pi I)^-1 H^H Y / sqrt(Pi) per subcarrier (driver:40-45,444-448)."""
+    return linear_detect(cfg, ebno_db, h, y_cp)

@@ -257,6 +257,133 @@ def case_legacy():
     save("legacy", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# Driver-side helper functions (round 3).  The driver scripts run a whole simulation at import and
+# need pyldpc, so they are NOT imported: the file is parsed with `ast`, and only its top-level
+# `def` nodes and the two `_TDLB_*` tables are compiled into a namespace holding numpy / math /
+# scipy.sparse.  The simulation body never runs and nothing is copied into the repo: the fixture
+# holds seeded inputs and the reference functions' outputs.
+DRIVERS = {
+    "v2": "/root/reference/system_model_2/Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py",       # :17-119, :125-177
+    "nbf": "/root/reference/system_model_2/OFDM_MIMO_2-2_NBF_LDPC.py",                 # :22-111
+    "siso": "/root/reference/system_model_2/Demo_SISO_QPSK_AWGN_LDPC_ESN_with_ZF_LS.py",  # :15-95
+}
+
+
+def driver_functions(path):
+    import ast
+    import math
+    import scipy.sparse as sp
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef):
+            keep.append(node)
+        elif isinstance(node, ast.Assign) and all(isinstance(t, ast.Name) and t.id.startswith("_TDLB_")
+                                                  for t in node.targets):
+            keep.append(node)
+    ns = {"np": np, "math": math, "sp": sp}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def case_driver_funcs():
+    """Pins for the detector tail, the LLR leg, the linear equalisers and the TDL-B tap recipe:
+    constellation + bit labels, hard decisions, ESN output reconstruction, MMSE / ZF per-subcarrier
+    solves, max-log LLRs, decision-directed sigma^2, logistic calibration, TDL-B impulse responses."""
+    rs = np.random.RandomState(20260)
+    out = {}
+    for tag, path in DRIVERS.items():
+        f = driver_functions(path)
+        for m in (2, 4, 6):
+            const = f["unit_qam_constellation"](m)
+            out[f"{tag}_qam{m}"] = const
+            out[f"{tag}_labels{m}"] = f["qam_bit_labels"](2 ** m, m)
+        for m in (2, 4):
+            const = np.array(f["unit_qam_constellation"](m)).astype(complex)
+            labels = f["qam_bit_labels"](2 ** m, m)
+            n, n_t = 64, (1 if tag == "siso" else 3)
+            # symbols = constellation points + noise, some far outside the grid, a few exact ties avoided
+            idx = rs.randint(0, 2 ** m, size=(n, n_t))
+            x = const[idx] + 0.35 * (rs.randn(n, n_t) + 1j * rs.randn(n, n_t))
+            x[::7] *= 3.0
+            out[f"{tag}_hard{m}_x"] = x
+            if tag == "v2":
+                out[f"{tag}_hard{m}_bits"] = f["hard_bits_from_syms"](x, const, m)
+            elif tag == "nbf":
+                out[f"{tag}_hard{m}_bits"] = f["hard_bits_from_syms"](x, const, m, None)
+            else:
+                out[f"{tag}_hard{m}_bits"] = f["hard_bits_from_syms"](x[:, 0], const, m, None)
+            z = x[:, 0].copy()
+            s2 = f["est_sigma2_from_decision"](z, const)
+            out[f"{tag}_sigma2_{m}"] = np.float64(s2)
+            out[f"{tag}_llr{m}"] = np.asarray(f["qam_llrs_maxlog"](z, const, labels, s2)).reshape(n, m)
+            out[f"{tag}_llr{m}_tiny_sigma"] = np.asarray(f["qam_llrs_maxlog"](z[:4], const, labels, 0.0)).reshape(4, m)
+            if tag != "siso":
+                # one frame the way the drivers do it (v2 :459-463): sigma^2 = mean over tx of the per-column
+                # estimates, every column's LLRs scaled by that mean
+                s2f = np.mean([f["est_sigma2_from_decision"](x[:, tx], const) for tx in range(n_t)])
+                out[f"{tag}_frame_sigma2_{m}"] = np.float64(s2f)
+                out[f"{tag}_frame_llr{m}"] = np.stack(
+                    [np.asarray(f["qam_llrs_maxlog"](x[:, tx], const, labels, s2f)).reshape(n, m) for tx in range(n_t)],
+                    axis=2)                                                     # (N, m, N_t)
+        # linear equalisers
+        if tag == "siso":
+            yk = rs.randn(16) + 1j * rs.randn(16)
+            hk = rs.randn(16) + 1j * rs.randn(16)
+            out[f"{tag}_eq_y"], out[f"{tag}_eq_h"] = yk, hk
+            out[f"{tag}_eq_zf"] = np.array([f["equalize_zf"](yk[i], hk[i], 0.37) for i in range(16)])
+            out[f"{tag}_eq_ls"] = np.array([f["equalize_ls"](yk[i], hk[i], 0.37) for i in range(16)])
+            out[f"{tag}_eq_mmse"] = np.array([f["equalize_mmse"](yk[i], hk[i], 0.37, 0.02) for i in range(16)])
+        else:
+            for (n_r, n_t) in ((8, 4), (2, 2)):
+                k = 16
+                hk = (rs.randn(k, n_r, n_t) + 1j * rs.randn(k, n_r, n_t)) / np.sqrt(2)
+                yk = rs.randn(k, n_r) + 1j * rs.randn(k, n_r)
+                key = f"{tag}_eq{n_r}x{n_t}"
+                out[key + "_h"], out[key + "_y"] = hk, yk
+                out[key + "_mmse"] = np.array([f["equalize_mmse"](yk[i], hk[i], 0.0123, 0.004) for i in range(k)])
+                out[key + "_zf"] = np.array([f["equalize_zf"](yk[i], hk[i], 0.0123) for i in range(k)])
+        # ESN output reconstruction: a common delay (what every driver uses) and per-column delays
+        if tag != "siso":
+            n, n_t = 16, 3
+            y = rs.randn(n + 9, 2 * n_t)
+            for name, delay, dmin in (("common", np.full(2 * n_t, 3), 3), ("ragged", np.array([2, 4, 3, 3, 5, 2]), 2)):
+                xs = f["reconstruct_esn_outputs_generic"](y, delay, dmin, n, n_t)
+                out[f"{tag}_recon_{name}"] = np.array(xs)
+                out[f"{tag}_recon_{name}_delay"] = delay
+                out[f"{tag}_recon_{name}_dmin"] = dmin
+            out[f"{tag}_recon_y"] = y
+            # the block-fading drivers ask for N+1 rows of an N-row array (OFDM_MIMO_2-2_NBF_LDPC.py:56-64)
+            xs = f["reconstruct_esn_outputs_generic"](y[:n], np.full(2 * n_t, 3), 3, n, n_t)
+            out[f"{tag}_recon_short"] = np.array(xs)
+    f = driver_functions(DRIVERS["v2"])
+    # logistic LLR calibration at the call site's arguments (driver :519-520) and at the defaults
+    x = 4.0 * rs.randn(600)
+    y = (rs.rand(600) < 1.0 / (1.0 + np.exp(0.8 * x - 0.2))).astype(float)
+    out["v2_logreg_x"], out["v2_logreg_y"] = x, y
+    out["v2_logreg_call"] = np.array(f["fit_logreg_1d"](x, y, maxiter=400, lr=0.1, l2=1e-3))
+    out["v2_logreg_default"] = np.array(f["fit_logreg_1d"](x, y))
+    out["v2_sigmoid"] = f["sigmoid"](np.linspace(-30, 30, 13))
+    # TDL-B taps: the driver's call (:321) at two seeds, plus the standard normals it consumed
+    # (per link, per path: real then imaginary) so a device generator can be fed the same gains
+    for seed in (1234 + 12 + 1, 1234 + 30 + 76):
+        taps = np.array(f["build_cdlb_mimo_taps"](8, 4, 8, 2 * 1.024e6, 300.0, seed=seed))
+        out[f"v2_taps_{seed}"] = taps
+        out[f"v2_taps_{seed}_normals"] = np.random.default_rng(seed).standard_normal((8, 4, 23, 2))
+    out["v2_taps_2x2_ds1000"] = np.array(f["build_cdlb_mimo_taps"](2, 2, 8, 2 * 1.024e6, 1000.0, seed=5))
+    out["v2_taps_2x2_ds1000_normals"] = np.random.default_rng(5).standard_normal((2, 2, 23, 2))
+    out["v2_tdlb_delays"], out["v2_tdlb_pow_db"] = f["_TDLB_NORM_DELAYS"], f["_TDLB_POW_DB"]
+    # the encoder call (driver :90-93) with a dense and a sparse generator
+    import scipy.sparse as sp
+    g = (rs.rand(24, 12) < 0.3).astype(np.int64)
+    u = (rs.rand(12) < 0.5).astype(np.int64)
+    out["v2_enc_g"], out["v2_enc_u"] = g, u
+    out["v2_enc_dense"] = f["ldpc_encode_bits"](g, u)
+    out["v2_enc_sparse"] = f["ldpc_encode_bits"](sp.csr_matrix(g), u)
+    save("driver_funcs", **out)
+
+
 def main():
     only = set(sys.argv[1:])          # e.g. `make_golden.py mackey scan` regenerates just those
     if only:
@@ -268,6 +395,7 @@ def main():
     case_mackey()
     case_scan()
     case_legacy()
+    case_driver_funcs()
     case_plain("tiny", 3, 2, 8, 12, seed=42, transient=2,
                kw=dict(spectral_radius=0.9, sparsity=0.25, input_scaling=[0.3, 0.2, 0.1],
                        input_shift=[0.0, 0.1, -0.1], teacher_scaling=0.5, teacher_shift=0.05))

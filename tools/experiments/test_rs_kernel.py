@@ -1,7 +1,11 @@
 """Register-resident-state fp16 / bf16 predict kernel (csrc/esn_recur_rs.hip; N_res 257..512, n_in 13..16,
 n_out <= 8: the headline shape; opt-in by the debug knob rs=1 -- it is correct but measured slower than the
 default) against the LDS-state kernel on identical inputs and identical noise draws and against
-the CPU oracle."""
+the CPU oracle.
+
+Not part of tests/: the kernel is compiled only into the experiment build
+    ESN_WITH_RS=1 python esn_ofdm_mimo_amd/build.py --variant rs
+    ESN_HIP_LIB=esn_ofdm_mimo_amd/libesn_hip_rs.so python -m pytest tools/experiments/test_rs_kernel.py -m gpu"""
 import numpy as np
 import pytest
 
