@@ -31,7 +31,9 @@ the same workload (N=1 only):
     `large_reservoir`  the fp16 step at N_res = 2048 (BASELINE configs[4]; one GEMM launch per timestep)
 `cpu_baseline` times the NumPy oracle (the reference algorithm, one frame per call, float64) on
 this host on bounded samples of the same workload: one BLAS thread, default BLAS threads, and one
-single-threaded process per core over disjoint block shards (`value`).
+single-threaded process per physical core over disjoint block shards (`value`).
+`sweep` is what a user of `DetectorSweep.run` gets: wall clock of an Eb/No sweep including the frame generator,
+training, detection and every host synchronisation.
 """
 import argparse
 import json
@@ -105,38 +107,82 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(shape, n_res, ebno, n_blocks, frames_per_block, max_procs=16):
-    """Three legs on bounded samples (each ~10 s): 1 BLAS thread, default BLAS threads, and one
-    single-threaded process per core over disjoint blocks.  `value` = the all-core figure."""
+def host_cores():
+    """(logical CPUs this process may run on, physical cores among them, CPU quota of the cgroup or None)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    phys = set()
+    for c in allowed:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            phys.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            phys.add(("?", str(c)))
+    quota = None
+    try:                                              # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                          # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return len(allowed), len(phys), quota
+
+
+def profiler_attached():
+    """True under rocprofv3 & co: their preloaded library initialises the GPU in every child process, so the
+    CPU legs (which fork worker processes) are skipped there."""
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("HSA_TOOLS_LIB", "") + os.environ.get("ROCP_TOOL_LIB", "")
+    return any(k in pre for k in ("rocprof", "roctracer", "rocprofiler"))
+
+
+def cpu_baseline(shape, n_res, ebno, n_blocks, frames_per_block, max_procs=0):
+    """Three legs on bounded samples (each ~10 s).  `value` = ONE single-threaded process per PHYSICAL core
+    the process may use (capped by the cgroup's CPU quota when there is one, never by a constant), each over
+    its own disjoint blocks.  Order: the process-per-core leg first, from a spawn context started before
+    this process has run any BLAS or GPU code; then one process with one BLAS thread; then one process
+    with the default BLAS threading."""
     import multiprocessing as mp
     n_t, n_r, n_sub, m = shape
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    procs = max(1, min(avail, max_procs))
+    logical, physical, quota = host_cores()
+    procs = physical
+    if quota is not None:
+        procs = min(procs, max(1, int(quota + 0.5)))
+    if max_procs:
+        procs = min(procs, max_procs)
     job = lambda first, nb, thr: (n_t, n_r, n_sub, m, n_res, ebno, first, nb, frames_per_block, thr)   # noqa: E731
-    n1, dt1, e1, b1 = _cpu_shard(job(0, n_blocks, 1))
-    nd, dtd, _, _ = _cpu_shard(job(0, n_blocks, 0))
     per = max(1, n_blocks // 2)                     # blocks per worker: about half the single-process sample
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(procs) as pool:          # fork: nothing here has touched the GPU yet
-        res = pool.map(_cpu_shard, [job(1000 * (w + 1), per, 1) for w in range(procs)])
+    with mp.get_context("spawn").Pool(procs) as pool:
+        res = pool.map(_cpu_shard, [job(1000 * (w + 1), per, 1) for w in range(procs)], chunksize=1)
     wall = time.perf_counter() - t0
     n_all = sum(r[0] for r in res)
     dt_all = max(r[1] for r in res)                 # timed regions run side by side; the slowest bounds the rate
+    n1, dt1, e1, b1 = _cpu_shard(job(0, n_blocks, 1))
+    nd, dtd, _, _ = _cpu_shard(job(0, n_blocks, 0))
     legs = {
         "single_thread": {"value": n1 / dt1, "cores": 1, "sample": f"{n_blocks} blocks x {frames_per_block} frames, {dt1:.1f} s"},
-        "default_blas_threads": {"value": nd / dtd, "cores": avail,
+        "default_blas_threads": {"value": nd / dtd, "cores": logical,
                                  "sample": f"{n_blocks} blocks x {frames_per_block} frames, {dtd:.1f} s, one process, BLAS default threading"},
         "process_per_core": {"value": n_all / dt_all, "cores": procs,
                              "sample": f"{procs} processes x {per} blocks x {frames_per_block} frames, 1 BLAS thread each, "
-                                       f"slowest {dt_all:.1f} s (wall incl. frame generation {wall:.1f} s)"},
+                                       f"slowest {dt_all:.1f} s (wall incl. process start, reservoir draw and frame "
+                                       f"generation {wall:.1f} s)"},
     }
     return dict(value=n_all / dt_all, unit="OFDM symbols/s", cores=procs, kind="port",
                 sample=f"train + detect with the NumPy float64 oracle (reference algorithm, one frame per call), "
-                       f"{procs} single-threaded processes x {per} blocks x {frames_per_block} frames; BER {e1 / max(b1, 1):.3f}",
-                host_cpu=_cpu_model(), host_cores_visible=avail, host_cores_total=os.cpu_count(), legs=legs)
+                       f"{procs} single-threaded processes (one per physical core"
+                       f"{'' if quota is None else ', capped by the cgroup CPU quota %.1f' % quota}) x {per} blocks x "
+                       f"{frames_per_block} frames; BER {e1 / max(b1, 1):.3f}",
+                host_cpu=_cpu_model(), host_logical_cpus=logical, host_physical_cores=physical,
+                host_cpu_quota=quota, host_cores_total=os.cpu_count(), legs=legs)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -226,6 +272,31 @@ def run_config(torch, dist, params, *, precision, fit_precision, reservoirs, n_r
                 n_in=sweep.n_in, n_out=sweep.n_out, T=T)
 
 
+def run_sweep(torch, params, *, precision, fit_precision, n_res, F, solve, reservoirs="shared", points=(6.0, 12.0, 18.0),
+              chunks_per_point=3):
+    """What a user of the harness gets: `DetectorSweep.run` over `points` Eb/No values, wall clock around the
+    whole call -- frame generation, training, detection, every host synchronisation and the final read-back of
+    the counters included (nothing is resident beforehand except the packed reservoir)."""
+    from esn_ofdm_mimo_amd.montecarlo import DetectorSweep
+    if fit_precision == "auto":
+        fit_precision = precision if precision in ("f16", "bf16") else ("f64" if precision == "f64" else "f32")
+    sweep = DetectorSweep(params, n_reservoir=n_res, noise=0.001, seed=1234, precision=precision,
+                          fit_precision=fit_precision, reservoirs=reservoirs, solve_method=solve)
+    chunk = sweep.default_chunk_blocks(F)
+    blocks = chunk * chunks_per_point
+    sweep.run([points[0]], chunk, frames_per_block=F)            # warm-up: allocator, packed images, code objects
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ber, counts = sweep.run(list(points), blocks, frames_per_block=F)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    frames = len(points) * blocks * F
+    return dict(value=frames / dt, unit="OFDM symbols/s", wall_s=dt, frames=frames, ebno_db=list(points),
+                blocks_per_point=blocks, chunk_blocks=chunk, ber=[float(b) for b in ber],
+                fits_repaired=int(sweep.fits_repaired), reservoir=reservoirs,
+                includes="frame generator + train + predict + detect + host syncs + counter read-back")
+
+
 def pmc_traffic(precision, G, F):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC pass taken on THIS
     workload (tools/pmc_traffic.py on the GPU box: FETCH_SIZE and WRITE_SIZE in separate passes,
@@ -286,7 +357,8 @@ def main():
     F = args.frames_per_block or params.coherence_symbols
 
     cpu = None
-    if not args.no_cpu_baseline and args.cpu_blocks > 0 and world == 1:   # once, at N=1, before the GPU is touched
+    if not args.no_cpu_baseline and args.cpu_blocks > 0 and world == 1 and not profiler_attached():
+        # once, at N=1, before this process touches the GPU or BLAS
         cpu = cpu_baseline((params.n_t, params.n_r, params.n_sub, params.m), args.n_res, args.ebno, args.cpu_blocks, F)
 
     import torch
@@ -339,6 +411,12 @@ def main():
                      kernel="esn::big_prep_kernel + esn::big_step_kernel, one pair of launches per timestep "
                             "(predict_kernel_ms spans all of them)")
 
+    sweep_rec = None
+    if not args.no_extra and world == 1 and not args.predict_only:
+        sweep_rec = run_sweep(torch, params, precision=args.precision, fit_precision=args.fit_precision,
+                              n_res=args.n_res, F=F, solve=args.solve)
+        sweep_rec["vs_headline"] = sweep_rec["value"] / head["value"]
+
     traffic, traffic_src = pmc_traffic(args.precision, G, F)
     if rank == 0:
         out = {
@@ -378,6 +456,8 @@ def main():
             out["reservoirs"] = extra_res
         if large:
             out["large_reservoir"] = large
+        if sweep_rec:
+            out["sweep"] = sweep_rec
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

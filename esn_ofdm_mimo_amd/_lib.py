@@ -38,9 +38,12 @@ SIGNATURES = {
                                     C.c_double, C.c_int, _dp, C.c_uint64, C.c_uint64, _dp, _vp, C.c_size_t, _vp]),
     "esn_predict_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(Shape), C.c_int, C.c_int]),
     "esn_harvest_batch": (C.c_int, [C.c_int, C.POINTER(Shape), _vp, _dp, _dp, _dp, _dp, _dp, _dp,
-                                    C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, C.c_uint64, _dp, _vp]),
+                                    C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, C.c_uint64, _dp,
+                                    _vp, C.c_size_t, _vp]),
+    "esn_harvest_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(Shape), C.c_int]),
     "esn_harvest_batch_f32": (C.c_int, [C.c_int, C.POINTER(Shape), _vp, _dp, _dp, _dp, _dp, _dp, _dp,
-                                        C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, C.c_uint64, _vp, _vp]),
+                                        C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.c_uint64, C.c_uint64, _vp,
+                                        _vp, C.c_size_t, _vp]),
     "esn_readout_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "esn_readout_solve_batch": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           _dp, _dp, _dp, _ip, _vp, _vp]),

@@ -140,10 +140,17 @@ class ReservoirBank:
             fn = self.lib.esn_harvest_batch_f32 if f32 else self.lib.esn_harvest_batch
             E = torch.empty((g, t, self.n_reservoir + self.n_inputs),
                             dtype=torch.float32 if f32 else torch.float64, device=self.device)
+            # reservoirs beyond 1024 units harvest as one GEMM launch per step out of a caller-owned workspace
+            wbytes = self.lib.esn_harvest_workspace_bytes(PRECISIONS[precision], C.byref(self.shape), g)
+            ws = None
+            if wbytes:
+                ws = getattr(self, "_harvest_ws", None)
+                if ws is None or ws.numel() < wbytes:
+                    ws = self._harvest_ws = torch.empty(wbytes, dtype=torch.uint8, device=self.device)
             check(fn(PRECISIONS[precision], C.byref(self.shape), ptr(self.packed_weights(precision)),
                      ptr(self.in_scale), ptr(self.in_shift), ptr(self.t_scale), ptr(self.t_shift),
                      ptr(U), ptr(D), g, t, self.noise, nm, ptr(nz), int(seed) & (2**64 - 1), int(group_offset),
-                     ptr(E), _lib.stream_handle()), "esn_harvest_batch")
+                     ptr(E), ptr(ws), wbytes, _lib.stream_handle()), "esn_harvest_batch")
         return E
 
     def chol_fits(self, rows, cols):

@@ -25,6 +25,9 @@ bool big_path_applies(int precision, const RecurParams& p);
 int big_slots(const RecurParams& p);
 size_t big_workspace_bytes(int n_slots, int Mp, int Kp);
 int launch_recur_big(int precision, const RecurParams& p, size_t wo_big_off, void* workspace, hipStream_t stream);
+bool big_harvest_applies(int precision, const RecurParams& p);
+size_t big_harvest_workspace_bytes(int n_groups, int Kp);
+int launch_harvest_big(int precision, const RecurParams& p, void* workspace, hipStream_t stream);
 // esn_recur_mfma.hip
 bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
@@ -329,10 +332,20 @@ size_t esn_predict_workspace_bytes(int precision, const esn_shape_t* shape, int 
     return big_workspace_bytes(big_slots(p), p.g.Mp, p.g.Kp);
 }
 
+size_t esn_harvest_workspace_bytes(int precision, const esn_shape_t* shape, int n_groups) {
+    RecurParams p;
+    if (n_groups <= 0) return 0;
+    if (fill_common(p, precision, shape, "esn_harvest_workspace_bytes", true)) return 0;
+    p.harvest = 1; p.n_groups = n_groups;
+    if (!p.g.big || !big_harvest_applies(precision, p)) return 0;
+    return big_harvest_workspace_bytes(n_groups, p.g.Kp);
+}
+
 static int harvest_common(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
                       const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
                       const double* D, int n_groups, int T, double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, uint64_t group_offset, double* E, float* E32, void* stream) {
+                      uint64_t seed, uint64_t group_offset, double* E, float* E32, void* workspace,
+                      size_t workspace_bytes, void* stream) {
     RecurParams p;
     int rc = fill_common(p, precision, shape, "esn_harvest_batch", true);
     if (rc) return rc;
@@ -368,6 +381,14 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     if ((((uintptr_t)E) | ((uintptr_t)E32)) & 15) return fail(-1, "esn_harvest_batch: E must be 16-byte aligned");
     p.E = E; p.E32 = E32;
     ESN_SET_STAMPS(p);
+    // large reservoirs: one GEMM launch per step when the caller lends a workspace (else the persistent kernel)
+    if (workspace && knobs().big_gemm && p.g.big && big_harvest_applies(precision, p)) {
+        const size_t need = big_harvest_workspace_bytes(n_groups, p.g.Kp);
+        if (workspace_bytes < need)
+            return fail(-1, "esn_harvest_batch: workspace holds %zu bytes, esn_harvest_workspace_bytes says %zu",
+                        workspace_bytes, need);
+        return hip_fail(launch_harvest_big(precision, p, workspace, (hipStream_t)stream), "esn_harvest_batch");
+    }
     int e = m64 ? launch_recur_f64_mfma(p, (hipStream_t)stream)
             : (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
                                      : launch_recur_mfma(precision, p, (hipStream_t)stream);
@@ -377,19 +398,21 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
 int esn_harvest_batch(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
                       const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
                       const double* D, int n_groups, int T, double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, uint64_t group_offset, double* E, void* stream) {
+                      uint64_t seed, uint64_t group_offset, double* E, void* workspace, size_t workspace_bytes,
+                      void* stream) {
     if (!E) return fail(-1, "esn_harvest_batch: null pointer");
     return harvest_common(precision, shape, packed_w, in_scale, in_shift, t_scale, t_shift, U, D, n_groups, T, noise,
-                          noise_mode, noise_u, seed, group_offset, E, nullptr, stream);
+                          noise_mode, noise_u, seed, group_offset, E, nullptr, workspace, workspace_bytes, stream);
 }
 
 int esn_harvest_batch_f32(int precision, const esn_shape_t* shape, const void* packed_w, const double* in_scale,
                           const double* in_shift, const double* t_scale, const double* t_shift, const double* U,
                           const double* D, int n_groups, int T, double noise, int noise_mode,
-                          const double* noise_u, uint64_t seed, uint64_t group_offset, float* E, void* stream) {
+                          const double* noise_u, uint64_t seed, uint64_t group_offset, float* E, void* workspace,
+                          size_t workspace_bytes, void* stream) {
     if (!E) return fail(-1, "esn_harvest_batch_f32: null pointer");
     return harvest_common(precision, shape, packed_w, in_scale, in_shift, t_scale, t_shift, U, D, n_groups, T, noise,
-                          noise_mode, noise_u, seed, group_offset, nullptr, E, stream);
+                          noise_mode, noise_u, seed, group_offset, nullptr, E, workspace, workspace_bytes, stream);
 }
 
 size_t esn_readout_solve_workspace_bytes(int n_groups, int rows, int cols, int n_out) {

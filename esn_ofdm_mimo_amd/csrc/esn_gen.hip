@@ -10,6 +10,7 @@
 //   gen_frames_kernel  bits -> QAM (:406-411) -> N*ifft (:416) -> CP (:417) -> sqrt(Pi) -> PA (:419)
 //                      -> per-link FIR, zero initial state (:422-425) -> AWGN (:426)
 #include "esn_common.h"
+#include <type_traits>
 
 namespace esn {
 
@@ -90,12 +91,21 @@ __global__ void gen_taps_kernel(TapParams tp) {
     }
 }
 
+// One workgroup per frame.  LDS: X[n_t][N] (frequency -> time in place), xpa[n_t][T] (post-PA signal),
+// tw[N/2] (twiddles, one table per workgroup instead of a sincospi per butterfly).  The channel is the
+// hot part -- T n_r outputs of n_t isi complex MACs each -- and is register-blocked: a wave takes 64
+// consecutive time samples and four receive antennas, so every x[t-k][tx] is read from LDS once per FOUR
+// outputs (consecutive lanes, consecutive addresses: conflict-free) and the taps are wave-uniform, i.e.
+// scalar loads straight from the tap array (round 2 kept them in LDS and read them with an 8-way bank
+// conflict per MAC: 75 % of the LDS cycles were conflicts, 6.2 ms per 153 600 frames).
+constexpr int GEN_RXG = 4;      // receive antennas per wave task
+
 __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const int N = fp.n_sub, T = N + fp.cp, n_t = fp.n_t, n_r = fp.n_r, isi = fp.isi, m = fp.m;
     double2* X = reinterpret_cast<double2*>(gsm);            // [n_t][N]   freq -> time (in place)
     double2* xpa = X + (size_t)n_t * N;                       // [n_t][T]   post-PA time signal
-    double2* ctap = xpa + (size_t)n_t * T;                    // [n_r][n_t][isi]
+    double2* tw = xpa + (size_t)n_t * T;                      // [N/2]      exp(+2 pi i k / N)
     const int tid = threadIdx.x, nth = blockDim.x;
     const int frame = blockIdx.x;
     const int blk = frame / fp.frames_per_block;
@@ -103,10 +113,13 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
     const Philox ph{(uint32_t)fp.seed, (uint32_t)(fp.seed >> 32)};
     const int side = 1 << (m / 2);
     const double norm = sqrt(2.0 * (double)(side * side - 1) / 3.0);
+    const int half = N >> 1;
 
-    for (int i = tid; i < n_r * n_t * isi; i += nth)
-        ctap[i] = make_double2(fp.taps[((size_t)blk * n_r * n_t * isi + i) * 2],
-                               fp.taps[((size_t)blk * n_r * n_t * isi + i) * 2 + 1]);
+    for (int k = tid; k < half; k += nth) {
+        double sn, cs;
+        sincospi(2.0 * (double)k / (double)N, &sn, &cs);
+        tw[k] = make_double2(cs, sn);
+    }
     // ---- bits -> constellation point (index = sum_b bit_b 2^b = i*side + j; Re = pam[i], Im = pam[j])
     for (int e = tid; e < N * n_t; e += nth) {
         const int sc = e / n_t, tx = e % n_t;
@@ -129,18 +142,16 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
     }
     __syncthreads();
     // ---- x = N * ifft(X): un-normalised inverse DFT, radix-2 DIT on bit-reversed input, per tx
-    const int half = N >> 1;
     for (int s = 1; s <= fp.log2n; ++s) {
-        const int hm = 1 << (s - 1);
+        const int hm = 1 << (s - 1), tstep = N >> s;
         for (int e = tid; e < n_t * half; e += nth) {
             const int tx = e / half, b = e % half;
             const int j = b & (hm - 1);
             const int base = ((b >> (s - 1)) << s) + j;
-            double sn, cs;
-            sincospi((double)j / (double)hm, &sn, &cs);      // w = exp(+2 pi i j / 2^s)
+            const double2 w = tw[j * tstep];                 // exp(+2 pi i j / 2^s), same argument as sincospi(j / hm)
             double2* xx = X + (size_t)tx * N;
             const double2 a = xx[base], c = xx[base + hm];
-            const double tr = c.x * cs - c.y * sn, ti = c.x * sn + c.y * cs;
+            const double tr = c.x * w.x - c.y * w.y, ti = c.x * w.y + c.y * w.x;
             xx[base] = make_double2(a.x + tr, a.y + ti);
             xx[base + hm] = make_double2(a.x - tr, a.y - ti);
         }
@@ -164,30 +175,79 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
     __syncthreads();
     // ---- y[t][rx] = sum_tx sum_k c[rx][tx][k] x_pa[t-k][tx] + sqrt(T No / 2) (n_re + j n_im)
     const double sig = sqrt((double)T * fp.no * 0.5);
-    for (int e = tid; e < T * n_r; e += nth) {
-        const int t = e / n_r, rx = e % n_r;
-        double yr = 0.0, yi = 0.0;
-        for (int tx = 0; tx < n_t; ++tx) {
-            const double2* c = ctap + ((size_t)rx * n_t + tx) * isi;
-            const double2* xs = xpa + (size_t)tx * T;
-            const int kmax = t < isi - 1 ? t : isi - 1;
-            for (int k = 0; k <= kmax; ++k) {
-                const double2 cv = c[k], xv = xs[t - k];
-                yr += cv.x * xv.x - cv.y * xv.y;
-                yi += cv.x * xv.y + cv.y * xv.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
+    const int t_chunks = (T + 63) >> 6, rx_groups = (n_r + GEN_RXG - 1) / GEN_RXG;
+    const double* taps_blk = fp.taps + (size_t)blk * n_r * n_t * isi * 2;
+    for (int task = wave; task < t_chunks * rx_groups; task += nwaves) {
+        const int rx0 = __builtin_amdgcn_readfirstlane((task / t_chunks) * GEN_RXG);
+        const int t = (task % t_chunks) * 64 + lane;
+        const bool live = t < T;
+        double yr[GEN_RXG], yi[GEN_RXG];
+#pragma unroll
+        for (int q = 0; q < GEN_RXG; ++q) { yr[q] = 0.0; yi[q] = 0.0; }
+        // taps: wave-uniform addresses read through the constant address space, i.e. s_load into SGPRs (the tap
+        // array was written by an earlier launch, so the scalar cache is coherent with it)
+        typedef const __attribute__((address_space(4))) double* cptr_t;
+        auto uniform_ptr = [](const double* q) -> cptr_t {           // both halves through readfirstlane: provably SGPRs
+            const uint64_t a = (uint64_t)q;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+            return (cptr_t)(((uint64_t)hi << 32) | lo);
+        };
+        auto channel = [&](auto isi_tag) {
+            constexpr int ISI = decltype(isi_tag)::value;            // 0 = run-time tap count
+            const int ntap = ISI ? ISI : isi;
+            for (int tx = 0; tx < n_t; ++tx) {
+                const double2* xs = xpa + (size_t)tx * T;
+                if constexpr (ISI > 0) {
+                    double2 xv[ISI];
+#pragma unroll
+                    for (int k = 0; k < ISI; ++k)                      // zero initial state (lfilter)
+                        xv[k] = (live && k <= t) ? xs[t - k] : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int q = 0; q < GEN_RXG; ++q) {
+                        const int rx = rx0 + q < n_r ? rx0 + q : n_r - 1;     // (uniform; clamped, result unused)
+                        cptr_t c = uniform_ptr(taps_blk + ((size_t)rx * n_t + tx) * ISI * 2);
+#pragma unroll
+                        for (int k = 0; k < ISI; ++k) {
+                            const double cr = c[2 * k], ci = c[2 * k + 1];
+                            yr[q] += cr * xv[k].x - ci * xv[k].y;
+                            yi[q] += cr * xv[k].y + ci * xv[k].x;
+                        }
+                    }
+                } else {
+                    for (int k = 0; k < ntap; ++k) {
+                        const double2 xv = (live && k <= t) ? xs[t - k] : make_double2(0.0, 0.0);
+#pragma unroll
+                        for (int q = 0; q < GEN_RXG; ++q) {
+                            const int rx = rx0 + q < n_r ? rx0 + q : n_r - 1;
+                            cptr_t c = uniform_ptr(taps_blk + (((size_t)rx * n_t + tx) * isi + k) * 2);
+                            const double cr = c[0], ci = c[1];
+                            yr[q] += cr * xv.x - ci * xv.y;
+                            yi[q] += cr * xv.y + ci * xv.x;
+                        }
+                    }
+                }
             }
+        };
+        if (isi == 8) channel(std::integral_constant<int, 8>{}); else channel(std::integral_constant<int, 0>{});
+        if (!live) continue;
+#pragma unroll
+        for (int q = 0; q < GEN_RXG; ++q) {
+            const int rx = rx0 + q;
+            if (rx >= n_r) break;
+            double nr, ni;
+            if (fp.noise_in) {
+                nr = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rx];
+                ni = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rx + 1];
+            } else {
+                uint32_t w[4];
+                ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_NOISE, (uint32_t)(t * n_r + rx), w);
+                box_muller(w[0], w[1], nr, ni);
+            }
+            reinterpret_cast<double2*>(fp.y_cp)[((size_t)frame * T + t) * n_r + rx] =
+                make_double2(yr[q] + sig * nr, yi[q] + sig * ni);
         }
-        double nr, ni;
-        if (fp.noise_in) {
-            nr = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rx];
-            ni = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rx + 1];
-        } else {
-            uint32_t w[4];
-            ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_NOISE, (uint32_t)e, w);
-            box_muller(w[0], w[1], nr, ni);
-        }
-        fp.y_cp[((size_t)frame * T + t) * n_r * 2 + 2 * rx] = yr + sig * nr;
-        fp.y_cp[((size_t)frame * T + t) * n_r * 2 + 2 * rx + 1] = yi + sig * ni;
     }
 }
 
@@ -199,8 +259,7 @@ int launch_gen_taps(const TapParams& tp, hipStream_t stream) {
 
 int launch_gen_frames(const FrameGenParams& fp, hipStream_t stream) {
     const int T = fp.n_sub + fp.cp;
-    const size_t lds = sizeof(double2) * ((size_t)fp.n_t * fp.n_sub + (size_t)fp.n_t * T +
-                                          (size_t)fp.n_r * fp.n_t * fp.isi);
+    const size_t lds = sizeof(double2) * ((size_t)fp.n_t * fp.n_sub + (size_t)fp.n_t * T + fp.n_sub / 2);
     if (lds > 150 * 1024) return -1;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gen_frames_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -415,6 +415,329 @@ bool big_path_applies(int precision, const RecurParams& p) {
 }
 int big_slots(const RecurParams& p) { return round_up(p.n_groups * round_up(p.F, 16), 256); }
 
+// =====================================================================================================
+// Harvest (teacher-forced state collection of ESN.fit, pyESN.py:176-182) on the same launch-per-step
+// GEMM.  A fit has ONE pilot per trained ESN, i.e. few columns (512 at the benchmark size), so the tile
+// is cut for workgroup count instead of reuse: 128 rows x 64 pilots, 4 waves (one per SIMD) of 64 x 32
+// each -- Mp/128 x n_slots/64 workgroups (128 at 2048 x 512) where the predict tile would give 16 and the
+// persistent kernel ran 16 workgroups of 16 waves at 1.9 % of the MFMA peak.  Teacher forcing makes the
+// step simpler than predict: no read-out, and [U_{s+1} ; F_{s+1}] depend on the inputs only, so the row
+// tile m = 0 of every pilot tile writes them in its epilogue and there is ONE launch per step.
+//   * operands by LDS-DMA in 1 KB fragments, FOUR 64-deep chunks in flight (24 KB each: 4 row tiles +
+//     2 pilot tiles x 4 k-groups), counted vmcnt, ONE barrier per chunk (a buffer is refilled three
+//     chunks after it was read, behind the barrier every wave passes after reading it);
+//   * epilogue: tanh + state noise -> operand type -> next state image; the same values, as float32 /
+//     float64, go through an LDS transpose so that the extended-state rows leave in 512-byte runs
+//     (E[pilot][s+1][128 rows]) instead of 16-byte pieces 1 MB apart.
+struct BigHarvestParams {
+    RecurParams r;
+    int n_slots;          // padded pilot axis, multiple of 64
+    int n_mt;             // row tiles of 128: Mp / 128
+    int nkgS, nkg;
+    int step;
+    const char* x_in;
+    char* x_out;
+};
+constexpr int BH_NST = 4;                              // chunks in flight
+constexpr int BH_STAGE = 24576;                        // A 16 KB + B 8 KB
+constexpr int BH_LDS = BH_NST * BH_STAGE;              // 96 KB (the epilogue's 33 KB transpose scratch aliases it)
+constexpr int BH_ELD = 132;                            // floats per pilot row of the transpose scratch (128 + pad)
+
+size_t big_harvest_workspace_bytes(int n_groups, int Kp) { return 2 * (size_t)round_up(n_groups, 64) * Kp * 2; }
+
+// [U_s ; F_s] of pilot slot `slot` -> the two k-groups behind the state groups of `img` (inputs row s + 1
+// scaled, teacher row s scaled: pyESN.py:180-182; the same float conversions as the persistent harvest)
+template <typename TR>
+__device__ __forceinline__ void bigh_write_uf(const BigHarvestParams& hp, char* img, int slot, int s) {
+    const RecurParams& p = hp.r;
+    const int n_in = p.n_in, n_out = p.n_out;
+    const int kin_p = p.g.kfb - p.g.kin;
+    const bool live = slot < p.n_groups;
+    const size_t fr = live ? (size_t)slot : 0;
+    const int T = p.S + 1;
+    const int row = s + 1;
+    float uu[16], ff[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ic = i < n_in ? i : 0;
+        const double raw = (row < T) ? p.U[(fr * T + (row < T ? row : 0)) * n_in + ic] : 0.0;
+        const double sc = p.in_scale ? p.in_scale[fr * n_in + ic] : 1.0;
+        const double sh = p.in_shift ? p.in_shift[fr * n_in + ic] : 0.0;
+        uu[i] = (live && i < n_in) ? (float)(raw * sc + sh) : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int oc = o < n_out ? o : 0;
+        const double raw = p.D[(fr * T + s) * n_out + oc];
+        const double sc = p.t_scale ? p.t_scale[fr * n_out + oc] : 1.0;
+        const double sh = p.t_shift ? p.t_shift[fr * n_out + oc] : 0.0;
+        ff[o] = (live && o < n_out && p.teacher_forcing) ? (float)(raw * sc + sh) : 0.f;
+    }
+    const int ct = slot >> 5, lr = slot & 31;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float e8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 16 * g2 + 8 * hh + e;              // k - kin
+                float v = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v = (kk == i) ? uu[i] : v;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) v = (kk == kin_p + o) ? ff[o] : v;
+                e8[e] = v;
+            }
+            char* d = img + ((size_t)ct * hp.nkg + hp.nkgS + g2) * 1024 + (size_t)(lr + 32 * hh) * 16;
+            *reinterpret_cast<u32x2*>(d) = pack4<typename TR::elem>(e8[0], e8[1], e8[2], e8[3]);
+            *reinterpret_cast<u32x2*>(d + 8) = pack4<typename TR::elem>(e8[4], e8[5], e8[6], e8[7]);
+        }
+}
+
+// both state images zero (X_0 = 0: a fit starts from the zero state, pyESN.py:177), then [U_0 ; F_0]
+template <typename TR>
+__global__ void bigh_init_kernel(BigHarvestParams hp, char* x0_img, char* x1_img) {
+    const size_t n = (size_t)(hp.n_slots / 32) * hp.nkg * 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        *reinterpret_cast<u32x4*>(x0_img + i * 16) = u32x4{0, 0, 0, 0};
+        *reinterpret_cast<u32x4*>(x1_img + i * 16) = u32x4{0, 0, 0, 0};
+    }
+}
+template <typename TR>
+__global__ void bigh_uf0_kernel(BigHarvestParams hp, char* x0_img) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot < hp.n_slots) bigh_write_uf<TR>(hp, x0_img, slot, 0);
+}
+// E[:, 0, :n_res] = 0 and the scaled-input columns of every row (pyESN.py:179,189)
+__global__ void bigh_fill_e_kernel(BigHarvestParams hp) {
+    const RecurParams& p = hp.r;
+    const int T = p.S + 1, ncols = p.n_res + p.n_in;
+    const size_t n_in_el = (size_t)p.n_groups * T * p.n_in, n_z = (size_t)p.n_groups * p.n_res;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_in_el + n_z; i += (size_t)gridDim.x * blockDim.x) {
+        size_t idx; double v = 0.0;
+        if (i < n_in_el) {
+            const int ci = (int)(i % p.n_in);
+            const size_t ft = i / p.n_in;                       // fr * T + t
+            const size_t fr = ft / T;
+            const double sc = p.in_scale ? p.in_scale[fr * p.n_in + ci] : 1.0;
+            const double sh = p.in_shift ? p.in_shift[fr * p.n_in + ci] : 0.0;
+            v = p.U[i] * sc + sh;
+            idx = ft * ncols + p.n_res + ci;
+        } else {
+            const size_t j = i - n_in_el;
+            idx = (j / p.n_res) * T * ncols + (j % p.n_res);
+        }
+        if (p.E32) p.E32[idx] = (float)v; else p.E[idx] = v;
+    }
+}
+
+template <typename TR, int NOISE>
+__global__ __launch_bounds__(256) void bigh_step_kernel(BigHarvestParams hp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RecurParams& p = hp.r;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;             // 2 x 2 waves: rows 64 wm.., pilots 32 wn..
+    const int r = lane & 31, h = lane >> 5;
+    const int n_res = p.n_res, nkg = hp.nkg;
+    const int n_ft = hp.n_slots >> 6;
+    // workgroup -> (row tile m, pilot tile n): an XCD keeps a contiguous band of row tiles (its slice of the
+    // weights stays in that L2) and sees every pilot tile
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    int m, n;
+    if (hp.n_mt % 8 == 0) { const int per = hp.n_mt / 8; m = xcd * per + local % per; n = local / per; }
+    else { m = local % hp.n_mt; n = (local / hp.n_mt) * 8 + xcd; }
+    if (n >= n_ft) return;
+    const int slot0 = n * 64;
+
+    const int lane16 = lane * 16;
+    const size_t x_bytes = (size_t)hp.n_slots * p.g.Kp * 2;
+    auto uniform_rsrc = [](const void* ptr, int bytes) {
+        const uint64_t a = (uint64_t)reinterpret_cast<uintptr_t>(ptr);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>((uintptr_t)(((uint64_t)hi << 32) | lo)), 0,
+                                                 __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t a_rsrc = uniform_rsrc(p.packed_w, (int)p.wset_stride);
+    const __amdgpu_buffer_rsrc_t b_rsrc = uniform_rsrc(hp.x_in, (int)x_bytes);
+    // per chunk: wave w fetches row tile w of A (4 k-groups) and half a pilot tile of B (2 k-groups)
+    const int a_src = (m * 4 + wave) * nkg;
+    const int b_src = ((slot0 >> 5) + wn) * nkg + 2 * wm;
+    auto issue = [&](int c, int buf) {
+        char* st = smem + (size_t)buf * BH_STAGE;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(st + (wave * 4 + kg) * 1024),
+                                                     16, lane16, (a_src + 4 * c + kg) * 1024, 0, 0);
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(st + 16384 + (wn * 4 + 2 * wm + kg) * 1024),
+                                                     16, lane16, (b_src + 4 * c + kg) * 1024, 0, 0);
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    auto compute = [&](int buf) {
+        const char* ab = smem + (size_t)buf * BH_STAGE + (size_t)(wm * 2) * 4096 + lane16;
+        const char* bb = smem + (size_t)buf * BH_STAGE + 16384 + (size_t)wn * 4096 + lane16;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const u32x4 b = *reinterpret_cast<const u32x4*>(bb + kg * 1024);
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(ab + kg * 1024);
+            const u32x4 a1 = *reinterpret_cast<const u32x4*>(ab + 4096 + kg * 1024);
+            TR::mma32(acc[0], a0, b);
+            TR::mma32(acc[1], a1, b);
+        }
+    };
+    const int nch = nkg / 4;
+#pragma unroll
+    for (int c = 0; c < BH_NST - 1; ++c)
+        if (c < nch) issue(c, c);
+    for (int c = 0; c < nch; ++c) {
+        // this wave's six pieces of chunk c have landed when at most the later chunks' are outstanding
+        if (c + 2 < nch) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // everybody's pieces of chunk c; chunk c-1 read by all
+        if (c + BH_NST - 1 < nch) issue(c + BH_NST - 1, (c + BH_NST - 1) & (BH_NST - 1));
+        compute(c & (BH_NST - 1));
+    }
+    __syncthreads();                                           // stage buffers free: the transpose scratch aliases them
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    const float noise = (float)p.noise;
+    const float n_c1 = noise * (1.0f / 256.0f), n_c0 = noise * (0.5f / 256.0f - 0.5f);
+    const __amdgpu_buffer_rsrc_t xo_rsrc = __builtin_amdgcn_make_buffer_rsrc(hp.x_out, 0, (int)x_bytes, 0x00020000);
+    float* es = reinterpret_cast<float*>(smem);                // [64 pilots][BH_ELD]
+    const int fcol = wn * 32 + r;
+    const int slot = slot0 + fcol;
+    const int fr = slot < p.n_groups ? slot : -1;
+    const int ct_g = (slot0 >> 5) + wn;
+    uint32_t key = 0;
+    const double* nz = nullptr;
+    if (NOISE == ESN_NOISE_COUNTER) key = noise_key(p.seed, (uint32_t)fr + p.frame_off, (uint32_t)hp.step);
+    if (NOISE == ESN_NOISE_TENSOR && fr >= 0) nz = p.noise_u + ((size_t)fr * p.S + hp.step) * n_res;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int rt_l = wm * 2 + mt, rt_g = m * 4 + rt_l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = rt_g * 32 + 8 * q + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[mt][4 * q + j]);
+            if (NOISE == ESN_NOISE_COUNTER) {
+                const uint32_t sq = noise_quad(key, (uint32_t)(row >> 2));
+                v[0] = fmaf((float)(sq & 0xffU), n_c1, v[0] + n_c0);
+                v[1] = fmaf((float)((sq >> 8) & 0xffU), n_c1, v[1] + n_c0);
+                v[2] = fmaf((float)((sq >> 16) & 0xffU), n_c1, v[2] + n_c0);
+                v[3] = fmaf((float)(sq >> 24), n_c1, v[3] + n_c0);
+            } else if (NOISE == ESN_NOISE_TENSOR) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+            }
+            typedef typename TR::elem EL;
+            const EL e0 = (EL)v[0], e1 = (EL)v[1], e2 = (EL)v[2], e3 = (EL)v[3];     // the state IS the rounded value
+            typedef EL vec4 __attribute__((ext_vector_type(4)));
+            const u32x2 xh = __builtin_bit_cast(u32x2, (vec4){e0, e1, e2, e3});
+            const int soff = ((ct_g * nkg + 2 * rt_g + (q >> 1)) * 64 + 32 * (q & 1)) * 16;
+            __builtin_amdgcn_raw_buffer_store_b64(xh, xo_rsrc, r * 16 + 8 * h, soff, 0);
+            *reinterpret_cast<f32x4*>(es + (size_t)fcol * BH_ELD + rt_l * 32 + 8 * q + 4 * h) =
+                f32x4{(float)e0, (float)e1, (float)e2, (float)e3};
+        }
+    }
+    __syncthreads();
+    // extended-state row s+1, rows [128 m, 128 m + 128) of every pilot of the tile: a wave writes two pilots per
+    // instruction, 512 (float32) or 1024 (float64) contiguous bytes each
+    {
+        const int ncols = n_res + p.n_in;
+        const int T = p.S + 1;
+        const int rr = 4 * (lane & 31);
+        const int row0 = m * 128 + rr;
+        const bool vec_ok = (n_res % 4 == 0) && (ncols % 4 == 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = wave * 16 + 2 * i + (lane >> 5);
+            const int sl = slot0 + f;
+            if (sl >= p.n_groups) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(es + (size_t)f * BH_ELD + rr);
+            const size_t base = ((size_t)sl * T + hp.step + 1) * ncols + row0;
+            if (vec_ok && row0 + 3 < n_res) {
+                if (p.E32) {
+                    *reinterpret_cast<f32x4*>(p.E32 + base) = v;
+                } else {
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f64x2*>(p.E + base) = f64x2{(double)v[0], (double)v[1]};
+                    *reinterpret_cast<f64x2*>(p.E + base + 2) = f64x2{(double)v[2], (double)v[3]};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (row0 + j < n_res) { if (p.E32) p.E32[base + j] = v[j]; else p.E[base + j] = (double)v[j]; }
+            }
+        }
+    }
+    // the next step's [U ; F] k-groups of this pilot tile
+    if (m == 0 && hp.step + 1 < p.S && tid < 64) bigh_write_uf<TR>(hp, hp.x_out, slot0 + tid, hp.step + 1);
+}
+
+template <typename TR>
+static int launch_bigh_t(const RecurParams& rp, void* workspace, hipStream_t stream) {
+    BigHarvestParams hp;
+    hp.r = rp;
+    const int Mp = rp.g.Mp, Kp = rp.g.Kp;
+    hp.n_slots = round_up(rp.n_groups, 64);
+    hp.n_mt = Mp / 128;
+    hp.nkgS = Mp / 16;
+    hp.nkg = Kp / 16;
+    char* ws = reinterpret_cast<char*>(workspace);
+    const size_t xb = (size_t)hp.n_slots * Kp * 2;
+    char* X[2] = {ws, ws + xb};
+    hp.step = 0; hp.x_in = X[0]; hp.x_out = X[1];
+    hipLaunchKernelGGL(bigh_init_kernel<TR>, dim3(1024), dim3(256), 0, stream, hp, X[0], X[1]);
+    hipLaunchKernelGGL(bigh_uf0_kernel<TR>, dim3((hp.n_slots + 255) / 256), dim3(256), 0, stream, hp, X[0]);
+    hipLaunchKernelGGL(bigh_fill_e_kernel, dim3(1024), dim3(256), 0, stream, hp);
+    const int n_ft = hp.n_slots / 64;
+    const dim3 grid(hp.n_mt % 8 == 0 ? hp.n_mt * n_ft : 8 * ((n_ft + 7) / 8) * hp.n_mt);
+    const void* k_none = reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_NONE>);
+    const void* k_tens = reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_TENSOR>);
+    const void* k_cnt = reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_COUNTER>);
+    hipError_t e = hipFuncSetAttribute(rp.noise_mode == ESN_NOISE_NONE ? k_none : rp.noise_mode == ESN_NOISE_TENSOR ? k_tens : k_cnt,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BH_LDS);
+    if (e != hipSuccess) return (int)e;
+    for (int s = 0; s < rp.S; ++s) {
+        hp.step = s; hp.x_in = X[s & 1]; hp.x_out = X[(s + 1) & 1];
+        switch (rp.noise_mode) {
+            case ESN_NOISE_NONE:
+                hipLaunchKernelGGL((bigh_step_kernel<TR, ESN_NOISE_NONE>), grid, dim3(256), BH_LDS, stream, hp); break;
+            case ESN_NOISE_TENSOR:
+                hipLaunchKernelGGL((bigh_step_kernel<TR, ESN_NOISE_TENSOR>), grid, dim3(256), BH_LDS, stream, hp); break;
+            default:
+                hipLaunchKernelGGL((bigh_step_kernel<TR, ESN_NOISE_COUNTER>), grid, dim3(256), BH_LDS, stream, hp); break;
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+// shapes the harvest GEMM serves: fp16/bf16, shared reservoir, reservoirs beyond 1024 units
+bool big_harvest_applies(int precision, const RecurParams& p) {
+    return (precision == ESN_F16 || precision == ESN_BF16) && p.harvest && p.n_wsets == 1 && p.n_res > 1024 &&
+           p.n_in <= 16 && p.n_out <= 8 && p.g.Mp % 128 == 0 && p.g.Kp % 64 == 0 && p.g.Kp / 64 >= BH_NST &&
+           p.g.Kp - p.g.Mp >= 32 && p.g.kfb - p.g.kin + round_up(p.n_out, 4) <= 32 &&
+           (size_t)round_up(p.n_groups, 64) * p.g.Kp * 2 < 0x7fffffffu && p.wset_stride < 0x7fffffffu;
+}
+
+int launch_harvest_big(int precision, const RecurParams& p, void* workspace, hipStream_t stream) {
+    if (precision == ESN_F16) return launch_bigh_t<TraitsF16>(p, workspace, stream);
+    if (precision == ESN_BF16) return launch_bigh_t<TraitsBF16>(p, workspace, stream);
+    return -1;
+}
+
 int launch_recur_big(int precision, const RecurParams& p, size_t wo_big_off, void* workspace, hipStream_t stream) {
     if (precision == ESN_F16) return launch_big_t<TraitsF16>(p, wo_big_off, workspace, stream);
     if (precision == ESN_BF16) return launch_big_t<TraitsBF16>(p, wo_big_off, workspace, stream);

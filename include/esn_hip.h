@@ -162,17 +162,22 @@ int esn_predict_batch(int precision, const esn_shape_t* shape,
  *   noise_u [n_groups][T-1][n_res] when noise_mode == ESN_NOISE_TENSOR.
  *   group_offset: as in esn_predict_batch (noise key and weight set follow the GLOBAL group index);
  *   E is 16-byte aligned.
+ *   workspace: device scratch of esn_harvest_workspace_bytes(...) bytes, or NULL.  As for predict, only reservoirs
+ *   beyond 1024 units in fp16/bf16 use it (one tiled GEMM launch per timestep, 128 x 64 tiles: a fit has one
+ *   sequence per trained ESN, so the tile is cut for workgroup count); with NULL the persistent kernel runs.
  *   precision: ESN_F64 / ESN_F32 keep the states at (better than) float32; ESN_F16 / ESN_BF16
  *   harvest states rounded to the operand type (round-off ~6e-6 abs, far below the model's own
  *   state noise 2.9e-4 rms) -- statistically equivalent, not bit-comparable.
  */
+size_t esn_harvest_workspace_bytes(int precision, const esn_shape_t* shape, int n_groups);
 int esn_harvest_batch(int precision, const esn_shape_t* shape,
                       const void* packed_w,
                       const double* in_scale, const double* in_shift,
                       const double* t_scale, const double* t_shift,
                       const double* U, const double* D, int n_groups, int T,
                       double noise, int noise_mode, const double* noise_u,
-                      uint64_t seed, uint64_t group_offset, double* E, void* stream);
+                      uint64_t seed, uint64_t group_offset, double* E,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same harvest, extended states stored as float32 (MFMA precisions only: their state columns are
  * exactly representable, the scaled-input columns round at 6e-8 relative).  Halves the harvest's
@@ -184,7 +189,8 @@ int esn_harvest_batch_f32(int precision, const esn_shape_t* shape,
                           const double* t_scale, const double* t_shift,
                           const double* U, const double* D, int n_groups, int T,
                           double noise, int noise_mode, const double* noise_u,
-                          uint64_t seed, uint64_t group_offset, float* E, void* stream);
+                          uint64_t seed, uint64_t group_offset, float* E,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* W_out[g] = (pinv(E[g][transient:]) @ (D[g][transient:]*t_scale + t_shift)).T  (:191-192)
  *

@@ -94,3 +94,47 @@ def test_big_gemm_single_frame_and_no_workspace(mods):
     finally:
         lib.debug_set("big_gemm", "1")
     assert rel_err(a, b) < 2e-3
+
+
+@pytest.mark.parametrize("n_res,n_in,n_out,G,precision,e_dtype", [(2048, 16, 8, 70, "f16", "f32"), (2048, 16, 8, 5, "f16", "f64"),
+                                                                 (1500, 4, 4, 129, "f16", "f32"), (2048, 16, 8, 33, "bf16", "f32")])
+@pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3), ("tensor", 1e-3)])
+def test_big_gemm_harvest_matches_persistent_kernel(mods, n_res, n_in, n_out, G, precision, e_dtype, noise_mode, noise):
+    """Teacher-forced harvest as one 128 x 64-tiled GEMM launch per step (bigh_step_kernel) against the persistent
+    harvest kernel on identical inputs and identical noise draws (ragged pilot counts: padding slots, partial
+    tiles), and against the CPU oracle's extended states."""
+    batched, lib = mods
+    (w, w_in, w_fb), rs = draw_weights_cached(n_res, n_in, n_out, n_res)
+    t = 24
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=noise)
+    in_scale, in_shift = rs.rand(G, n_in) * 0.2 + 0.1, rs.randn(G, n_in) * 0.05
+    t_scale, t_shift = rs.rand(G, n_out) * 0.2 + 0.1, rs.randn(G, n_out) * 0.02
+    bank.set_scaling(in_scale, in_shift, t_scale, t_shift)
+    u, d = rs.randn(G, t, n_in), rs.randn(G, t, n_out)
+    kw = dict(precision=precision, noise_mode=noise_mode, seed=9, e_dtype=e_dtype, group_offset=3)
+    if noise_mode == "tensor":
+        if (n_res, precision, G) != (2048, "f16", 70):
+            pytest.skip("tensor noise: one shape is enough")
+        kw["noise_u"] = rs.rand(G, t - 1, n_res)
+    from esn_ofdm_mimo_amd._lib import PRECISIONS
+    import ctypes as C
+    assert lib.load().esn_harvest_workspace_bytes(PRECISIONS[precision], C.byref(bank.shape), G) > 0
+    big = bank.harvest(u, d, **kw).double().cpu().numpy()
+    lib.debug_set("big_gemm", "0")
+    try:
+        persistent = bank.harvest(u, d, **kw).double().cpu().numpy()
+    finally:
+        lib.debug_set("big_gemm", "1")
+    assert big.shape == persistent.shape == (G, t, n_res + n_in)
+    # same operand rounding, same k order, same noise stream: the two kernels agree to accumulation round-off
+    tol = 2e-3 if precision == "f16" else 2e-2
+    assert rel_err(big, persistent) < tol, rel_err(big, persistent)
+    np.testing.assert_array_equal(big[:, :, n_res:], persistent[:, :, n_res:])          # scaled-input columns
+    assert np.all(big[:, 0, :n_res] == 0.0)
+    if noise == 0.0:
+        for g in (0, G - 1):
+            o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[g], input_shift=in_shift[g],
+                             teacher_scaling=t_scale[g], teacher_shift=t_shift[g], random_state=1)
+            o.W, o.W_in, o.W_feedb = w, w_in, w_fb
+            o.fit(u[g], d[g], 2)
+            assert rel_err(big[g], o._ext_states) < (2e-2 if precision == "f16" else 1e-1)
