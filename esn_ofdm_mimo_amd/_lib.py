@@ -47,10 +47,11 @@ SIGNATURES = {
     "esn_readout_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "esn_readout_solve_batch": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           _dp, _dp, _dp, _ip, _vp, _vp]),
+    "esn_readout_chol_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "esn_readout_solve_chol_batch": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                               _dp, _dp, _dp, _ip, _vp]),
+                                               _dp, _dp, _dp, _ip, _vp, C.c_size_t, _vp]),
     "esn_readout_solve_chol_batch_f32": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                                   _dp, _dp, _dp, _ip, _vp]),
+                                                   _dp, _dp, _dp, _ip, _vp, C.c_size_t, _vp]),
     "esn_gen_taps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _dp,
                                C.c_uint64, C.c_uint64, _dp, _vp]),
     "esn_gen_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

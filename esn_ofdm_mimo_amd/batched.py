@@ -151,18 +151,21 @@ class ReservoirBank:
                      ptr(self.in_scale), ptr(self.in_shift), ptr(self.t_scale), ptr(self.t_shift),
                      ptr(U), ptr(D), g, t, self.noise, nm, ptr(nz), int(seed) & (2**64 - 1), int(group_offset),
                      ptr(E), ptr(ws), wbytes, _lib.stream_handle()), "esn_harvest_batch")
+            if wbytes and precision == "f64" and g == 1:
+                self._cluster_err = ws[wbytes - 64:wbytes - 60]      # error word of the single-sequence cluster kernel
         return E
 
     def chol_fits(self, rows, cols):
-        """Shapes the LDS-resident Cholesky solve covers (esn_readout_solve_chol_batch)."""
-        return min(rows, cols) <= 128 and self.n_outputs <= 8
+        """Shapes the Cholesky solve covers (esn_readout_solve_chol_batch): Gram dimension up to 128 in LDS,
+        up to 512 out of a workspace."""
+        return min(rows, cols) <= 512 and self.n_outputs <= 8
 
     def solve(self, E, D, transient, method="qr"):
         """W_out[g] = (pinv(E[g][transient:]) @ scale(D[g][transient:])).T ; returns (W_out, status).
 
         method "qr": float64 Householder QR (accurate to cond(E) eps; the drop-in's choice).
-        method "chol": float64 normal equations, Gram + Cholesky in LDS (min(rows, cols) <= 128,
-        n_out <= 8), an order of magnitude faster; groups whose pivot test fails are re-solved
+        method "chol": float64 normal equations on the float64 matrix pipe (min(rows, cols) <= 512, n_out <= 8;
+        Gram + factor in LDS up to 128, in a workspace beyond), an order of magnitude faster; groups whose pivot test fails are re-solved
         with QR on the GPU.  "auto" = "chol" when the shape fits."""
         torch = self.torch
         e32 = isinstance(E, torch.Tensor) and E.dtype == torch.float32       # as written by harvest(e_dtype="f32")
@@ -177,13 +180,19 @@ class ReservoirBank:
             E = E.double()                                                  # the QR kernel works in place on float64
         if method == "chol":
             if not fits:
-                raise ValueError("method='chol' needs min(rows, cols) <= 128 and n_outputs <= 8")
+                raise ValueError("method='chol' needs min(rows, cols) <= 512 and n_outputs <= 8")
             with torch.cuda.device(self.device):
                 W_out = torch.empty((g, self.n_outputs, cols), dtype=torch.float64, device=self.device)
                 status = torch.empty(g, dtype=torch.int32, device=self.device)
                 fn = self.lib.esn_readout_solve_chol_batch_f32 if e32 else self.lib.esn_readout_solve_chol_batch
+                wbytes = self.lib.esn_readout_chol_workspace_bytes(g, rows, cols)
+                ws = None
+                if wbytes:
+                    ws = getattr(self, "_chol_ws", None)
+                    if ws is None or ws.numel() < wbytes:
+                        ws = self._chol_ws = torch.empty(wbytes, dtype=torch.uint8, device=self.device)
                 check(fn(ptr(E), ptr(D), g, t, int(transient), cols, self.n_outputs, ptr(self.t_scale),
-                         ptr(self.t_shift), ptr(W_out), ptr(status), _lib.stream_handle()),
+                         ptr(self.t_shift), ptr(W_out), ptr(status), ptr(ws), wbytes, _lib.stream_handle()),
                       "esn_readout_solve_chol_batch")
             self.last_solve_status = status        # checked lazily: no host sync on the fast path
             return W_out, status
@@ -261,7 +270,20 @@ class ReservoirBank:
                 ptr(self.t_scale), ptr(self.t_shift), ptr(U), b, int(frames_per_group), t_in, T,
                 int(transient), ptr(x0), ptr(y0), self.noise, nm, ptr(nz), int(seed) & (2**64 - 1),
                 int(group_offset), ptr(out), ptr(ws), wbytes, _lib.stream_handle()), "esn_predict_batch")
+            if wbytes and precision == "f64" and b == 1:
+                self._cluster_err = ws[wbytes - 64:wbytes - 60]      # error word of the single-sequence cluster kernel
         return out
+
+    def raise_if_cluster_timed_out(self):
+        """Host-synchronising check after a single-sequence float64 call (the 2-D drop-in makes it when it copies the
+        result to the host): the cluster kernel's workgroups wait for each other with bounded spins and raise an
+        error word instead of hanging (include/esn_hip.h, esn_predict_batch: workspace)."""
+        w = getattr(self, "_cluster_err", None)
+        if w is not None:
+            self._cluster_err = None
+            if int(w.view(self.torch.int32).item()) != 0:
+                raise _lib.EsnHipError("single-sequence cluster kernel: a workgroup timed out waiting for the others "
+                                       "(the device is oversubscribed); outputs are invalid")
 
     # ------------------------------------------------------------------ detector tail
     def detect_count(self, Y, tx_bits, p_i, frames_per_group, n_sub, n_t, bits_per_sym,

@@ -28,6 +28,10 @@ int launch_recur_big(int precision, const RecurParams& p, size_t wo_big_off, voi
 bool big_harvest_applies(int precision, const RecurParams& p);
 size_t big_harvest_workspace_bytes(int n_groups, int Kp);
 int launch_harvest_big(int precision, const RecurParams& p, void* workspace, hipStream_t stream);
+// esn_recur_cluster.hip
+bool cluster_applies(int precision, const RecurParams& p);
+size_t cluster_workspace_bytes(int n_res, int n_in, int n_out, bool harvest);
+int launch_recur_cluster(const RecurParams& p, void* workspace, hipStream_t stream);
 // esn_recur_mfma.hip
 bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
@@ -49,6 +53,10 @@ int launch_readout_solve(const double* E, const double* D, int n_groups, int T, 
 int launch_readout_chol(const double* E, const float* E32, const double* D, int n_groups, int T, int transient,
                         int cols, int n_out, const double* t_scale, const double* t_shift,
                         double* W_out, int* status, hipStream_t stream);
+size_t chol_big_work_doubles(int n);
+int launch_readout_chol_big(const double* E, const float* E32, const double* D, int n_groups, int T, int transient,
+                            int cols, int n_out, const double* t_scale, const double* t_shift,
+                            double* W_out, int* status, void* workspace, hipStream_t stream);
 // esn_gen.hip
 int launch_gen_taps(const TapParams& tp, hipStream_t stream);
 int launch_gen_frames(const FrameGenParams& fp, hipStream_t stream);
@@ -90,6 +98,8 @@ Knobs& knobs() {
         x.rs = (v && v[0] == '1') ? 1 : 0;          // opt-in: measured slower than the skewed LDS-state kernel
         v = getenv("ESN_BIG_GEMM");
         x.big_gemm = (v && v[0] == '0') ? 0 : 1;
+        v = getenv("ESN_CLUSTER");
+        x.cluster = (v && v[0] == '0') ? 0 : 1;
         return x;
     }();
     return k;
@@ -165,6 +175,7 @@ int esn_debug_set(const char* key, const char* value) {
 #endif
     }
     if (!strcmp(key, "big_gemm")) { k.big_gemm = (value && value[0] == '0') ? 0 : 1; return 0; }
+    if (!strcmp(key, "cluster")) { k.cluster = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }
 
@@ -298,6 +309,15 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
     if (((uintptr_t)Y & 15) != 0) return fail(-1, "esn_predict_batch: Y must be 16-byte aligned");
     p.Y = Y;
     ESN_SET_STAMPS(p);
+    // ONE float64 sequence (the reference's own call pattern): the matrix resident in the LDS of a cluster of
+    // workgroups that exchange the state through L2 every step (esn_recur_cluster.hip), when a workspace is lent
+    if (workspace && knobs().cluster && cluster_applies(precision, p)) {
+        const size_t need = cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, false);
+        if (workspace_bytes < need)
+            return fail(-1, "esn_predict_batch: workspace holds %zu bytes, esn_predict_workspace_bytes says %zu",
+                        workspace_bytes, need);
+        return hip_fail(launch_recur_cluster(p, workspace, (hipStream_t)stream), "esn_predict_batch");
+    }
     // large reservoirs: one GEMM launch per step when the caller lends a workspace (else the persistent kernel)
     if (workspace && knobs().big_gemm && p.g.big && big_path_applies(precision, p)) {
         const size_t need = big_workspace_bytes(big_slots(p), p.g.Mp, p.g.Kp);
@@ -326,8 +346,9 @@ size_t esn_predict_workspace_bytes(int precision, const esn_shape_t* shape, int 
     RecurParams p;
     if (n_frames <= 0 || frames_per_group <= 0) return 0;
     if (fill_common(p, precision, shape, "esn_predict_workspace_bytes")) return 0;
-    p.harvest = 0; p.F = frames_per_group;
+    p.harvest = 0; p.F = frames_per_group; p.n_frames = n_frames;
     p.n_groups = (n_frames + frames_per_group - 1) / frames_per_group;
+    if (knobs().cluster && cluster_applies(precision, p)) return cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, false);
     if (!p.g.big || !big_path_applies(precision, p)) return 0;
     return big_workspace_bytes(big_slots(p), p.g.Mp, p.g.Kp);
 }
@@ -336,7 +357,8 @@ size_t esn_harvest_workspace_bytes(int precision, const esn_shape_t* shape, int 
     RecurParams p;
     if (n_groups <= 0) return 0;
     if (fill_common(p, precision, shape, "esn_harvest_workspace_bytes", true)) return 0;
-    p.harvest = 1; p.n_groups = n_groups;
+    p.harvest = 1; p.n_groups = n_groups; p.n_frames = n_groups;
+    if (knobs().cluster && cluster_applies(precision, p)) return cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, true);
     if (!p.g.big || !big_harvest_applies(precision, p)) return 0;
     return big_harvest_workspace_bytes(n_groups, p.g.Kp);
 }
@@ -381,6 +403,13 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     if ((((uintptr_t)E) | ((uintptr_t)E32)) & 15) return fail(-1, "esn_harvest_batch: E must be 16-byte aligned");
     p.E = E; p.E32 = E32;
     ESN_SET_STAMPS(p);
+    if (workspace && knobs().cluster && !E32 && cluster_applies(precision, p)) {          // one float64 sequence
+        const size_t need = cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, true);
+        if (workspace_bytes < need)
+            return fail(-1, "esn_harvest_batch: workspace holds %zu bytes, esn_harvest_workspace_bytes says %zu",
+                        workspace_bytes, need);
+        return hip_fail(launch_recur_cluster(p, workspace, (hipStream_t)stream), "esn_harvest_batch");
+    }
     // large reservoirs: one GEMM launch per step when the caller lends a workspace (else the persistent kernel)
     if (workspace && knobs().big_gemm && p.g.big && big_harvest_applies(precision, p)) {
         const size_t need = big_harvest_workspace_bytes(n_groups, p.g.Kp);
@@ -431,26 +460,47 @@ int esn_readout_solve_batch(const double* E, const double* D, int n_groups, int 
                     "esn_readout_solve_batch");
 }
 
+size_t esn_readout_chol_workspace_bytes(int n_groups, int rows, int cols) {
+    if (n_groups <= 0 || rows <= 0 || cols <= 0) return 0;
+    const int n = rows < cols ? rows : cols;
+    if (n <= 128 || n > 512) return 0;             // LDS-resident kernel / not served
+    return sizeof(double) * chol_big_work_doubles(n) * (size_t)n_groups;
+}
+
+static int chol_common(const char* who, const double* E, const float* E32, const double* D, int n_groups, int T,
+                       int transient, int cols, int n_out, const double* t_scale, const double* t_shift, double* W_out,
+                       int* status, void* workspace, size_t workspace_bytes, void* stream) {
+    if ((!E && !E32) || !D || !W_out || !status) return fail(-1, "%s: null pointer", who);
+    if (n_groups <= 0 || T <= 0 || transient < 0 || transient >= T || cols <= 0 || n_out <= 0)
+        return fail(-1, "%s: invalid sizes", who);
+    const int rows = T - transient, n = rows < cols ? rows : cols;
+    if (n > 128) {            // Gram matrix and factor in the caller's workspace (esn_solve.hip, readout_chol_big_kernel)
+        const size_t need = esn_readout_chol_workspace_bytes(n_groups, rows, cols);
+        if (need == 0 || n_out > 8) return fail(-2, "%s: no kernel instance for this shape", who);
+        if (!workspace || workspace_bytes < need)
+            return fail(-1, "%s: workspace holds %zu bytes, esn_readout_chol_workspace_bytes says %zu", who,
+                        workspace ? workspace_bytes : (size_t)0, need);
+        if (((uintptr_t)(E ? (const void*)E : (const void*)E32) & 15) || ((uintptr_t)workspace & 15))
+            return fail(-1, "%s: E and the workspace must be 16-byte aligned", who);
+        return hip_fail(launch_readout_chol_big(E, E32, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
+                                                status, workspace, (hipStream_t)stream), who);
+    }
+    return hip_fail(launch_readout_chol(E, E32, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
+                                        status, (hipStream_t)stream), who);
+}
+
 int esn_readout_solve_chol_batch(const double* E, const double* D, int n_groups, int T, int transient, int cols,
                                  int n_out, const double* t_scale, const double* t_shift, double* W_out,
-                                 int* status, void* stream) {
-    if (!E || !D || !W_out || !status) return fail(-1, "esn_readout_solve_chol_batch: null pointer");
-    if (n_groups <= 0 || T <= 0 || transient < 0 || transient >= T || cols <= 0 || n_out <= 0)
-        return fail(-1, "esn_readout_solve_chol_batch: invalid sizes");
-    return hip_fail(launch_readout_chol(E, nullptr, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
-                                        status, (hipStream_t)stream),
-                    "esn_readout_solve_chol_batch");
+                                 int* status, void* workspace, size_t workspace_bytes, void* stream) {
+    return chol_common("esn_readout_solve_chol_batch", E, nullptr, D, n_groups, T, transient, cols, n_out, t_scale,
+                       t_shift, W_out, status, workspace, workspace_bytes, stream);
 }
 
 int esn_readout_solve_chol_batch_f32(const float* E, const double* D, int n_groups, int T, int transient, int cols,
                                      int n_out, const double* t_scale, const double* t_shift, double* W_out,
-                                     int* status, void* stream) {
-    if (!E || !D || !W_out || !status) return fail(-1, "esn_readout_solve_chol_batch_f32: null pointer");
-    if (n_groups <= 0 || T <= 0 || transient < 0 || transient >= T || cols <= 0 || n_out <= 0)
-        return fail(-1, "esn_readout_solve_chol_batch_f32: invalid sizes");
-    return hip_fail(launch_readout_chol(nullptr, E, D, n_groups, T, transient, cols, n_out, t_scale, t_shift, W_out,
-                                        status, (hipStream_t)stream),
-                    "esn_readout_solve_chol_batch_f32");
+                                     int* status, void* workspace, size_t workspace_bytes, void* stream) {
+    return chol_common("esn_readout_solve_chol_batch_f32", nullptr, E, D, n_groups, T, transient, cols, n_out, t_scale,
+                       t_shift, W_out, status, workspace, workspace_bytes, stream);
 }
 
 int esn_detect_count(const double* Y, int n_frames, int frames_per_group, int n_sub, int n_t, int bits_per_sym,

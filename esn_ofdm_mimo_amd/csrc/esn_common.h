@@ -196,6 +196,7 @@ struct Knobs {
     int rs;                // 1: fp16/bf16 predict at N_res 257..512 runs the register-resident-state kernel (default 0:
                            // correct but 17 % slower than the skewed LDS-state kernel on MI355X)
     int big_gemm;          // 1 (default): N_res > 1024 predict runs as one GEMM launch per step when a workspace is given
+    int cluster;           // 1 (default): ONE float64 sequence runs on the LDS-resident cluster kernel when a workspace is given
 };
 Knobs& knobs();
 

@@ -1,0 +1,263 @@
+// float64 recurrence of ONE sequence -- the reference's own call pattern (one `fit` / `predict` per OFDM
+// frame, pyESN.py:176-182,243-255) -- with the reservoir matrix RESIDENT IN LDS.
+//
+// A lone sequence is a chain of T dependent matrix-vector products; streaming the 2 MB float64 matrix
+// from L2 into one CU every step (esn_recur_f64.hip: ~36 us per step) is bound by that CU's L2 port.
+// Here a cluster of C co-resident workgroups holds the matrix for all T steps: workgroup c keeps rows
+// [cR, cR + R) of Wext = [W | W_in | W_feedb] in its LDS (K-major, R = 32 rows = 137 KB at N_res = 512,
+// C = 16) and per step
+//     gathers   x_{t-1} (and the read-out partials) of all C workgroups from L2,
+//     computes  its R rows of  x_t = tanh(Wext [x_{t-1}; u_t; y_{t-1}]) + noise,
+//               its partial    W_out[:, rows] x_t                       (predict),
+//     publishes both.
+// The hand-off is the guide's data-tagged granule form (MI355X_MICROARCH.md, Persistent kernels:
+// handoff-1to1 / allgather): every double travels as TWO naturally aligned 8-byte words {32 data bits,
+// step tag}, each written by one agent-scope (`sc1`) store and polled by agent-scope loads until the tag
+// reads the awaited step -- no flag, no fence, no grid barrier, no relaunch; the buffer is double-buffered
+// by step parity (a workgroup can only overwrite parity p after it has consumed every slice of the step in
+// between, which every other workgroup produces only after consuming the previous parity-p slices).
+// Every spin is bounded: a workgroup that waits longer than ~2 s of polls raises the error word and leaves,
+// and so does everybody else (the host call then reports the failure instead of hanging).
+// N_res small enough for one workgroup (C = 1) keeps the state in LDS and exchanges nothing.
+#include "esn_common.h"
+
+namespace esn {
+
+struct ClusterGeom {
+    int R;        // rows per workgroup (power of two, <= 256)
+    int C;        // workgroups
+    int K;        // n_res + n_in + n_out
+    int per;      // doubles a workgroup publishes per step: R (+ n_out when predicting)
+};
+
+constexpr int CL_NT = 256;
+constexpr uint32_t CL_SPIN_LIMIT = 1u << 22;     // polls per wait before giving up (each poll >= ~0.5 us)
+
+static bool cluster_geometry(int n_res, int n_in, int n_out, bool harvest, ClusterGeom* cg) {
+    const int K = n_res + n_in + n_out;
+    int R = 256;
+    while (R > 1 && (size_t)K * R * 8 > 138 * 1024) R >>= 1;
+    if ((size_t)K * R * 8 > 138 * 1024) return false;
+    while (R / 2 >= n_res && R > 1) R >>= 1;                 // do not hold more rows than there are
+    const int C = (n_res + R - 1) / R;
+    if (C > 64 || n_out > 16 || n_in > 64) return false;
+    cg->R = R; cg->C = C; cg->K = K; cg->per = R + (harvest ? 0 : n_out);
+    // LDS: matrix + operand vector + gathered partials + small tables; checked by the launcher
+    return true;
+}
+static size_t cluster_lds_bytes(const ClusterGeom& cg, int n_in, int n_out) {
+    return sizeof(double) * ((size_t)cg.K * cg.R            // Ws[k][R]
+                             + cg.K + 8                       // v = [x ; u ; fb]
+                             + (size_t)CL_NT                  // matvec partial sums
+                             + (size_t)cg.C * 16              // gathered read-out partials [C][n_out]
+                             + (size_t)16 * cg.R              // W_out[:, my rows]
+                             + (size_t)16 * n_in + 2 * n_in + cg.R + 64);      // + x slice of the step
+}
+size_t cluster_workspace_bytes(int n_res, int n_in, int n_out, bool harvest) {
+    ClusterGeom cg;
+    if (!cluster_geometry(n_res, n_in, n_out, harvest, &cg)) return 0;
+    if (cluster_lds_bytes(cg, n_in, n_out) > 158 * 1024) return 0;
+    return 2 * (size_t)cg.C * cg.per * 2 * 8 + 64;           // two parities of granules + the error word
+}
+
+template <bool HARVEST>
+__global__ __launch_bounds__(CL_NT) void recur_cluster_kernel(RecurParams p, ClusterGeom cg, unsigned long long* xch) {
+    extern __shared__ __attribute__((aligned(16))) char csm[];
+    const int n_res = p.n_res, n_in = p.n_in, n_out = p.n_out;
+    const int R = cg.R, C = cg.C, K = cg.K, per = cg.per;
+    double* Ws = reinterpret_cast<double*>(csm);              // [K][R]
+    double* v = Ws + (size_t)K * R;                           // [K]: x (n_res) | u (n_in) | fb (n_out)
+    double* psum = v + K + 8;                                 // [CL_NT]
+    double* pbuf = psum + CL_NT;                              // [C][16] read-out partials of the last step
+    double* wo_rows = pbuf + (size_t)C * 16;                  // [16][R]   W_out[o][cR + r]
+    double* wo_in = wo_rows + (size_t)16 * R;                 // [16][n_in] W_out[o][n_res + i]
+    double* u_prev = wo_in + (size_t)16 * n_in;               // [n_in] scaled inputs of the previous step
+    double* xs = u_prev + n_in;                               // [R] my rows of x_{s+1}
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x, row0 = c * R;
+    const int ncols = n_res + n_in;
+    const int out_rows = p.S - p.transient;
+    unsigned int* err = reinterpret_cast<unsigned int*>(xch + (size_t)2 * C * per * 2);
+    __shared__ int sh_dead;
+    if (tid == 0) sh_dead = 0;
+
+    // ---- resident operands ---------------------------------------------------------------------------
+    const double* Wk = reinterpret_cast<const double*>(p.packed_w);           // [K][n_res], K-major
+    for (int i = tid; i < K * R; i += CL_NT) {
+        const int k = i / R, r = i - k * R;
+        Ws[i] = (row0 + r < n_res) ? Wk[(size_t)k * n_res + row0 + r] : 0.0;
+    }
+    if (!HARVEST) {
+        const double* wo = reinterpret_cast<const double*>(p.packed_wout);    // plain W_out [n_out][ncols]
+        for (int i = tid; i < 16 * R; i += CL_NT) {
+            const int o = i / R, r = i - o * R;
+            wo_rows[i] = (o < n_out && row0 + r < n_res) ? wo[(size_t)o * ncols + row0 + r] : 0.0;
+        }
+        for (int i = tid; i < 16 * n_in; i += CL_NT) {
+            const int o = i / n_in, ci = i - o * n_in;
+            wo_in[i] = (o < n_out) ? wo[(size_t)o * ncols + n_res + ci] : 0.0;
+        }
+    }
+    for (int i = tid; i < K + 8; i += CL_NT) v[i] = 0.0;
+    for (int i = tid; i < n_in; i += CL_NT) u_prev[i] = 0.0;
+    __syncthreads();
+    if (C == 1) {                                             // the whole state is ours: start from x0 locally
+        for (int i = tid; i < n_res; i += CL_NT) v[i] = p.x0 ? p.x0[i] : 0.0;
+    }
+    auto scaled_input = [&](int row, int ci) -> double {
+        const double raw = (row < p.T_in) ? p.U[(size_t)row * n_in + ci] : 0.0;
+        const double sc = p.in_scale ? p.in_scale[ci] : 1.0, sh = p.in_shift ? p.in_shift[ci] : 0.0;
+        return raw * sc + sh;
+    };
+    if (HARVEST && c == 0) {                                  // E row 0 = [0, scale(u[0])]  (pyESN.py:179,189)
+        for (int i = tid; i < ncols; i += CL_NT)
+            p.E[i] = (i >= n_res) ? scaled_input(0, i - n_res) : 0.0;
+    }
+
+    // granule helpers: a double = two 8-byte words {tag << 32 | half}
+    auto publish = [&](int step_tag, int idx, double val) {   // idx < per
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, val);
+        unsigned long long* dst = xch + (((size_t)(step_tag & 1) * C + c) * per + idx) * 2;
+        const unsigned long long tag = (unsigned long long)(unsigned)step_tag << 32;
+        __hip_atomic_store(dst, tag | (bits & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // gather every workgroup's slice of step `step_tag` into v[0:n_res] and pbuf; false on time-out
+    auto gather = [&](int step_tag) -> bool {
+        const int total = C * per;
+        bool ok = true;
+        for (int i = tid; i < total; i += CL_NT) {
+            const unsigned long long* src = xch + ((size_t)(step_tag & 1) * C * per + i) * 2;
+            unsigned long long lo = 0, hi = 0;
+            uint32_t spins = 0;
+            while (true) {
+                lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(lo >> 32) == (unsigned)step_tag && (unsigned)(hi >> 32) == (unsigned)step_tag) break;
+                if (++spins > CL_SPIN_LIMIT ||
+                    ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const double val = __builtin_bit_cast(double, (hi << 32) | (lo & 0xffffffffULL));
+            const int cc = i / per, j = i - cc * per;
+            if (j < R) { if (cc * R + j < n_res) v[cc * R + j] = val; }
+            else pbuf[cc * 16 + (j - R)] = val;
+        }
+        if (!ok) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_dead = 1;
+        }
+        __syncthreads();
+        return sh_dead == 0;
+    };
+
+    // step tag t+1 carries x_t (t = 0: the start state) and, when predicting, the partials of y_t
+    if (C > 1) {
+        for (int r = tid; r < R; r += CL_NT)
+            publish(1, r, (p.x0 && row0 + r < n_res) ? p.x0[row0 + r] : 0.0);
+        if (!HARVEST)                                         // y_0 = lastoutput (continuation) or 0: workgroup 0 carries it whole
+            for (int o = tid; o < n_out; o += CL_NT) publish(1, R + o, (c == 0 && p.y0) ? p.y0[o] : 0.0);
+    } else if (!HARVEST) {
+        for (int o = tid; o < n_out; o += CL_NT) pbuf[o] = p.y0 ? p.y0[o] : 0.0;
+    }
+
+    const int kpart = tid / R, rr = tid - kpart * R;          // matvec: thread (k-part, row)
+    const int nkp = CL_NT / R;
+    for (int s = 0; s <= p.S; ++s) {
+        if (HARVEST && s == p.S) break;                       // (the last state is in E; nobody reads it back)
+        // ---- x_s and the partials of y_s ---------------------------------------------------------------
+        if (C > 1) { if (!gather(s + 1)) return; }
+        else __syncthreads();
+        // y_s = sum of partials + W_out[:, inputs] u_s   (pyESN.py:252; s = 0: the start feedback as is)
+        if (!HARVEST && tid < n_out) {
+            double y = 0.0;
+            for (int cc = 0; cc < C; ++cc) y += pbuf[cc * 16 + tid];
+            if (s > 0) for (int ci = 0; ci < n_in; ++ci) y = fma(wo_in[tid * n_in + ci], u_prev[ci], y);
+            v[n_res + n_in + tid] = y;
+            if (c == 0 && s > 0 && s - 1 >= p.transient) {                 // output row s-1, unscaled (pyESN.py:255)
+                const double sc = p.t_scale ? p.t_scale[tid] : 1.0, sh = p.t_shift ? p.t_shift[tid] : 0.0;
+                p.Y[(size_t)(s - 1 - p.transient) * n_out + tid] = (y - sh) / sc;
+            }
+        }
+        if (s == p.S) break;
+        // inputs of this step (row s + in_row_off); harvest: the teacher row s as feedback
+        if (tid < n_in) {
+            const double u = scaled_input(s + p.in_row_off, tid);
+            v[n_res + tid] = u;
+            u_prev[tid] = u;
+            if (HARVEST && c == 0) p.E[(size_t)(s + 1) * ncols + n_res + tid] = u;
+        }
+        if (HARVEST && tid >= 64 && tid < 64 + n_out) {
+            const int o = tid - 64;
+            const double sc = p.t_scale ? p.t_scale[o] : 1.0, sh = p.t_shift ? p.t_shift[o] : 0.0;
+            v[n_res + n_in + o] = p.teacher_forcing ? p.D[(size_t)s * n_out + o] * sc + sh : 0.0;
+        }
+        __syncthreads();
+        // ---- my R rows of Wext v ------------------------------------------------------------------------
+        double acc = 0.0;
+        for (int k = kpart; k < K; k += nkp) acc = fma(Ws[(size_t)k * R + rr], v[k], acc);
+        psum[tid] = acc;
+        __syncthreads();
+        double xn = 0.0;
+        if (tid < R) {
+            double z = 0.0;
+            for (int q = 0; q < nkp; ++q) z += psum[q * R + tid];
+            const int row = row0 + tid;
+            xn = tanh(z);
+            if (p.noise_mode == ESN_NOISE_TENSOR && row < n_res)
+                xn += p.noise * (p.noise_u[(size_t)s * n_res + row] - 0.5);
+            else if (p.noise_mode == ESN_NOISE_COUNTER)
+                xn += p.noise * ((double)noise_uniform(noise_key(p.seed, p.frame_off, (uint32_t)s), (uint32_t)row) - 0.5);
+            if (row >= n_res) xn = 0.0;
+            if (HARVEST && row < n_res) p.E[(size_t)(s + 1) * ncols + row] = xn;
+            if (C > 1) publish(s + 2, tid, xn);
+        }
+        if (C == 1) {
+            __syncthreads();                                  // everybody has read v: the state may be replaced
+            if (tid < R && tid < n_res) v[tid] = xn;
+        }
+        if (!HARVEST) {
+            // partial read-out of my rows: W_out[:, rows] x_{s+1}
+            if (tid < R) xs[tid] = xn;
+            __syncthreads();
+            if (tid < n_out) {
+                double part = 0.0;
+                for (int r = 0; r < R; ++r) part = fma(wo_rows[tid * R + r], xs[r], part);
+                if (C > 1) publish(s + 2, R + tid, part);
+                else pbuf[tid] = part;
+            }
+        }
+    }
+}
+
+bool cluster_applies(int precision, const RecurParams& p) {
+    if (precision != ESN_F64 || p.n_frames != 1 || p.n_groups != 1 || p.n_wsets != 1) return false;
+    return cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, p.harvest != 0) > 0;
+}
+
+int launch_recur_cluster(const RecurParams& p, void* workspace, hipStream_t stream) {
+    ClusterGeom cg;
+    if (!cluster_geometry(p.n_res, p.n_in, p.n_out, p.harvest != 0, &cg)) return -1;
+    const size_t lds = cluster_lds_bytes(cg, p.n_in, p.n_out);
+    const size_t ws = cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, p.harvest != 0);
+    hipError_t e = hipMemsetAsync(workspace, 0, ws, stream);           // step tags start at 1: zero = nothing published
+    if (e != hipSuccess) return (int)e;
+    unsigned long long* xch = reinterpret_cast<unsigned long long*>(workspace);
+    if (p.harvest) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(recur_cluster_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(recur_cluster_kernel<true>, dim3(cg.C), dim3(CL_NT), lds, stream, p, cg, xch);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(recur_cluster_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(recur_cluster_kernel<false>, dim3(cg.C), dim3(CL_NT), lds, stream, p, cg, xch);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace esn

@@ -21,6 +21,7 @@ struct SolveParams {
     double* work; size_t work_stride;   // doubles per group
     int m, n, wide;
     int skip;   // diagnostic only (ESN_CHOL_SKIP env): bit0 Gram, bit1 Cholesky, bit2 solves, bit3 W_out
+    int part_ok;   // big kernel: the three-partial-sums W_out pass fits the LDS the launcher allocated
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -575,6 +576,444 @@ int launch_readout_chol(const double* E, const float* E32, const double* D, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(readout_chol_kernel, dim3(n_groups), dim3(1024), lds, stream, sp);
+    return (int)hipGetLastError();
+}
+
+}  // namespace esn
+
+// ---------------------------------------------------------------------------------
+// The same normal-equations solve for Gram dimensions 129..512 (4x8 at N = 512: 512 x 528;
+// N_res = 300 at N = 512: 512 x 316), where neither the Gram matrix (2 MB) nor its factor fits LDS.
+// One workgroup per trained ESN, the Gram matrix / factor column-major in a caller workspace
+// (L2 / Infinity Cache resident), every O(n^3) part on the float64 matrix pipe:
+//   phase 1  G (lower 16x16 tiles) in passes of four tile columns: the k-chunks of A stream through
+//            LDS once per pass (double-buffered, register-prefetched), <= 8 accumulator tiles per wave
+//   phase 3  left-looking Cholesky by 16-column panels: panel tile (rt, j) = G(rt, j) - L(rt, :16j) L(j, :16j)^T
+//            with both operands read straight from the workspace in MFMA layout (column-major storage makes a
+//            lane group's 16 rows one 128-byte segment), then the 16x16 diagonal factorisation / inversion in
+//            registers and the panel solve by MFMA exactly as in the LDS kernel; the finished panel goes back
+//            to the workspace
+//   phase 4  column-oriented substitutions, one wave per right-hand side, the next column prefetched
+//   phase 5  W_out^T = A^T alpha (wide) -- the LDS kernel's pass over A
+// Same pivot rule (v <= 1e-14 max diag: direction dropped, group flagged) and the same arithmetic order per
+// tile as the LDS kernel, so the two agree to round-off where both apply.
+// ---------------------------------------------------------------------------------
+namespace esn {
+
+constexpr int CB_NMAX = 512;      // largest Gram dimension
+constexpr int CB_KC = 8;          // k-chunk staged per pass
+constexpr int CB_PLD = 17;        // LDS row stride of the panel (doubles)
+constexpr int CB_NT = 512;        // threads: 8 waves, two per SIMD -> 256 registers per lane (16 accumulator tiles)
+constexpr int CB_NW = CB_NT / 64;
+constexpr int CB_EPT = CB_NMAX * CB_KC / CB_NT;     // staged elements per thread
+constexpr int CB_TPW = 16;        // Gram tiles per wave and pass: ceil((32 + 31 + 30 + 29) / 8)
+
+size_t chol_big_work_doubles(int n) {
+    const size_t np = (size_t)round_up(n, 16);
+    return np * np;
+}
+
+__global__ __launch_bounds__(CB_NT) void readout_chol_big_kernel(SolveParams sp) {
+    extern __shared__ __attribute__((aligned(16))) char cb_smem[];
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    __shared__ int sh_bad;
+    __shared__ double sh_invd[CB_NMAX];
+    __shared__ double sh_linv[16][17];
+    __shared__ double sh_red[CB_NW];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int rows = sp.T - sp.transient, cols = sp.cols, nrhs = sp.n_out;
+    const bool wide = rows < cols;
+    const int n = wide ? rows : cols;      // Gram dimension
+    const int m = wide ? cols : rows;      // contraction length
+    const int np = round_up(n, 16), ntile = np / 16;
+    const int ld = np;
+    double* Gw = sp.work + (size_t)g * sp.work_stride;                  // [np][np] column-major, lower part
+    const size_t a_off = ((size_t)g * sp.T + sp.transient) * cols;
+    const double* A = sp.E ? sp.E + a_off : nullptr;
+    const float* A32 = sp.E32 ? sp.E32 + a_off : nullptr;
+    const double* Dg = sp.D + ((size_t)g * sp.T + sp.transient) * nrhs;
+    const int lr = lane & 15, lq = lane >> 4;
+    if (tid == 0) sh_bad = 0;
+
+    // ---- phase 1: Gram ----------------------------------------------------------------------------
+    {
+        const int AS_LD = np + 4;
+        double* Abuf[2] = {reinterpret_cast<double*>(cb_smem), reinterpret_cast<double*>(cb_smem) + (size_t)CB_KC * AS_LD};
+        const int ept = (np * CB_KC + CB_NT - 1) / CB_NT;             // staged elements per thread (<= CB_EPT)
+        double stg[CB_EPT];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int q = 0; q < CB_EPT; ++q) {
+                const int e = tid + CB_NT * q;
+                int kk, i;
+                if (wide) { i = e / CB_KC; kk = e % CB_KC; } else { kk = e / np; i = e % np; }
+                const int k = k0 + kk;
+                const size_t ai_ = wide ? (size_t)i * cols + k : (size_t)k * cols + i;
+                stg[q] = (q < ept && e < np * CB_KC && i < n && k < m) ? (A32 ? (double)A32[ai_] : A[ai_]) : 0.0;
+            }
+        };
+        auto commit = [&](double* dst) {
+#pragma unroll
+            for (int q = 0; q < CB_EPT; ++q) {
+                const int e = tid + CB_NT * q;
+                if (q < ept && e < np * CB_KC) {
+                    int kk, i;
+                    if (wide) { i = e / CB_KC; kk = e % CB_KC; } else { kk = e / np; i = e % np; }
+                    dst[kk * AS_LD + i] = stg[q];
+                }
+            }
+        };
+        const int fr_off = lq * AS_LD + lr;
+        const int n_pass = (ntile + 3) / 4;
+        for (int jb = 0; jb < n_pass; ++jb) {
+            // lower tiles of tile columns [4 jb, 4 jb + 4): t-th of them -> (ti, tj); wave w takes t = w, w + CB_NW, ...
+            const int tj0 = 4 * jb, tj1 = (tj0 + 4 < ntile) ? tj0 + 4 : ntile;
+            int cnt = 0;
+            for (int tj = tj0; tj < tj1; ++tj) cnt += ntile - tj;
+            int my_ti[CB_TPW], my_tj[CB_TPW];
+#pragma unroll
+            for (int q = 0; q < CB_TPW; ++q) {
+                int t = wvu + CB_NW * q, tj = tj0;
+                bool ok = t < cnt;
+                while (ok && t >= ntile - tj) { t -= ntile - tj; ++tj; }
+                my_tj[q] = ok ? tj : -1;
+                my_ti[q] = ok ? tj + t : 0;
+            }
+            f64x4 acc[CB_TPW];
+#pragma unroll
+            for (int q = 0; q < CB_TPW; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+            fetch(0);
+            commit(Abuf[0]);
+            __syncthreads();
+            int cur = 0;
+            for (int k0 = 0; k0 < m; k0 += CB_KC) {
+                const bool more = k0 + CB_KC < m;
+                if (more) fetch(k0 + CB_KC);
+                const double* Ac = Abuf[cur];
+#pragma unroll
+                for (int k4 = 0; k4 < CB_KC; k4 += 4) {
+                    const double* slab = Ac + k4 * AS_LD + fr_off;
+#pragma unroll
+                    for (int q = 0; q < CB_TPW; ++q)
+                        if (my_tj[q] >= 0)
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(slab[my_ti[q] * 16], slab[my_tj[q] * 16], acc[q], 0, 0, 0);
+                }
+                if (more) commit(Abuf[cur ^ 1]);
+                __syncthreads();
+                cur ^= 1;
+            }
+#pragma unroll
+            for (int q = 0; q < CB_TPW; ++q)
+                if (my_tj[q] >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        Gw[(size_t)(my_tj[q] * 16 + lr) * ld + my_ti[q] * 16 + 4 * i + lq] = acc[q][i];
+                }
+            __syncthreads();
+        }
+        // right-hand sides into LDS: Bs[o][np]
+        double* Bs = reinterpret_cast<double*>(cb_smem);
+        __syncthreads();
+        for (int e = tid; e < nrhs * np; e += CB_NT) {
+            const int o = e / np, i = e % np;
+            double v = 0.0;
+            if (wide && i < n) {
+                const double sc = sp.t_scale ? sp.t_scale[(size_t)g * nrhs + o] : 1.0;
+                const double sh = sp.t_shift ? sp.t_shift[(size_t)g * nrhs + o] : 0.0;
+                v = Dg[(size_t)i * nrhs + o] * sc + sh;
+            }
+            if (wide) Bs[e] = v;
+        }
+        if (!wide) {
+            // tall case: right-hand side A^T B, thread -> (o, i), one pass over A (consecutive lanes = consecutive columns)
+            for (int e = tid; e < nrhs * np; e += CB_NT) {
+                const int o = e / np, i = e % np;
+                double acc_b = 0.0;
+                if (i < n) {
+                    const double sc = sp.t_scale ? sp.t_scale[(size_t)g * nrhs + o] : 1.0;
+                    const double sh = sp.t_shift ? sp.t_shift[(size_t)g * nrhs + o] : 0.0;
+#pragma unroll 8
+                    for (int k = 0; k < m; ++k) {
+                        const double a = A32 ? (double)A32[(size_t)k * cols + i] : A[(size_t)k * cols + i];
+                        acc_b = fma(a, Dg[(size_t)k * nrhs + o] * sc + sh, acc_b);
+                    }
+                }
+                Bs[e] = acc_b;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    double* Bs = reinterpret_cast<double*>(cb_smem);                    // [nrhs][np]          (32 KB)
+    double* P = Bs + (size_t)8 * CB_NMAX;                                // [np][CB_PLD] panel  (68 KB)
+    // pivot tolerance from the largest diagonal entry
+    double dmax = 0.0;
+    for (int i = tid; i < n; i += CB_NT) dmax = fmax(dmax, Gw[(size_t)i * ld + i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_down(dmax, off));
+    if (lane == 0) sh_red[wv] = dmax;
+    __syncthreads();
+    double piv_tol = 0.0;
+    for (int w = 0; w < CB_NW; ++w) piv_tol = fmax(piv_tol, sh_red[w]);
+    piv_tol *= 1e-14;
+
+    auto bcast = [](double x, int src) -> double {
+        const uint64_t u = __builtin_bit_cast(uint64_t, x);
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, src);
+        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), src);
+        return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    };
+    // ---- phase 3: left-looking panel Cholesky ---------------------------------------------------------
+    for (int j = 0; j < ntile; ++j) {
+        const int j0 = 16 * j;
+        // (1) panel tiles: G(rt, j) - L(rt, :j0) L(j, :j0)^T
+        for (int rt = j + wvu; rt < ntile; rt += CB_NW) {
+            f64x4 c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = Gw[(size_t)(j0 + lr) * ld + rt * 16 + 4 * i + lq];
+            const double* la = Gw + (size_t)lq * ld + rt * 16 + lr;       // L[rt*16 + lr][k + lq]
+            const double* lb = Gw + (size_t)lq * ld + j0 + lr;            // L[j0 + lr][k + lq]
+#pragma unroll 4
+            for (int k = 0; k < j0; k += 4)
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[(size_t)k * ld], lb[(size_t)k * ld], c, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) P[(rt * 16 + 4 * i + lq) * CB_PLD + lr] = c[i];
+        }
+        __syncthreads();
+        // (2) diagonal block: factorise and invert in registers (wave 0), as in the LDS kernel
+        if (wv == 0) {
+            const int r = lane & 15;
+            double a[16], x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = P[(j0 + r) * CB_PLD + c];
+            double my_invd = 1.0;
+            unsigned rejected = 0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const double v = bcast(a[jj], jj);
+                const bool live = j0 + jj < n;
+                const bool ok = live && v > piv_tol;
+                if (live && !ok) rejected |= 1u << jj;
+                const double d = ok ? sqrt(v) : 1.0, inv_d = ok ? 1.0 / d : 0.0;
+                if (r == jj) my_invd = ok ? inv_d : 1.0;
+                a[jj] = (r == jj) ? d : ((r > jj) ? a[jj] * inv_d : 0.0);
+#pragma unroll
+                for (int k = jj + 1; k < 16; ++k) {
+                    const double lkj = bcast(a[jj], k);
+                    if (r >= k) a[k] = fma(-a[jj], lkj, a[k]);
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) P[(j0 + r) * CB_PLD + c] = a[c];
+                sh_invd[j0 + r] = my_invd;
+            }
+            if (rejected && lane == 0) sh_bad = 1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double sacc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) sacc = fma(-bcast(a[k], i), x[k], sacc);
+                const double idi = bcast(my_invd, i);
+                x[i] = (i >= r && !((rejected >> i) & 1u)) ? sacc * idi : 0.0;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh_linv[i][r] = x[i];
+            }
+        }
+        __syncthreads();
+        // (3) panel solve: L(rt, j) = P(rt) L11^-T
+        for (int rt = j + 1 + wvu; rt < ntile; rt += CB_NW) {
+            f64x4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4)
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(rt * 16 + lr) * CB_PLD + k0 + lq], sh_linv[lr][k0 + lq], c, 0, 0, 0);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) P[(rt * 16 + 4 * i + lq) * CB_PLD + lr] = c[i];
+        }
+        __syncthreads();
+        // (4) the finished panel (rows j0 .. np-1, 16 columns) back to the workspace, column-major
+        for (int e = tid; e < (np - j0) * 16; e += CB_NT) {
+            const int c = e / (np - j0), rr = j0 + e % (np - j0);
+            Gw[(size_t)(j0 + c) * ld + rr] = P[rr * CB_PLD + c];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    // ---- phase 4: L L^T x = b, one wave per right-hand side; lane holds rows lane + 64 s ---------------
+    if (wv < nrhs) {
+        double* xb = Bs + (size_t)wv * np;
+        constexpr int NS = CB_NMAX / 64;
+        const int ns = (np + 63) / 64;
+        double b[NS], l[NS], lnext[NS];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) b[s2] = (s2 < ns && lane + 64 * s2 < np) ? xb[lane + 64 * s2] : 0.0;
+        auto load_col = [&](double (&dst)[NS], int jc) {
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const int i = lane + 64 * s2;
+                dst[s2] = (s2 < ns && jc >= 0 && jc < n && i < n) ? Gw[(size_t)jc * ld + i] : 0.0;
+            }
+        };
+        auto pick = [&](const double (&v)[NS], int jc) -> double {        // element jc of the distributed vector
+            double own = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) own = ((jc >> 6) == s2) ? v[s2] : own;
+            return __shfl(own, jc & 63);
+        };
+        load_col(l, 0);
+        for (int jc = 0; jc < n; ++jc) {                                   // forward: L z = b
+            load_col(lnext, jc + 1);
+            const double zj = pick(b, jc) * sh_invd[jc];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const int i = lane + 64 * s2;
+                b[s2] = (i == jc) ? zj : ((i > jc) ? fma(-l[s2], zj, b[s2]) : b[s2]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) l[s2] = lnext[s2];
+        }
+        load_col(l, n - 1);
+        for (int jc = n - 1; jc >= 0; --jc) {                              // backward: L^T x = z
+            load_col(lnext, jc - 1);
+            double part = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const int i = lane + 64 * s2;
+                part = (i > jc && i < n) ? fma(l[s2], b[s2], part) : part;
+            }
+            part = wave_sum(part);
+            const double xj = (pick(b, jc) - part) * sh_invd[jc];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) b[s2] = (lane + 64 * s2 == jc) ? xj : b[s2];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) l[s2] = lnext[s2];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2)
+            if (s2 < ns && lane + 64 * s2 < np) xb[lane + 64 * s2] = b[s2];
+    }
+    __syncthreads();
+
+    // ---- phase 5: W_out ----------------------------------------------------------------------------------
+    if (wide) {
+        // W_out[o][c] = sum_i A[i][c] alpha[i][o]: every element of A fetched once by 16-byte loads; thread
+        // (part, unit) sums a share of the rows for the unit's 2 (float64) or 4 (float32) columns and all
+        // right-hand sides, the partial sums meet in LDS
+        double* part = P;                                                // [parts][8][cols] behind Bs
+        if (sp.part_ok) {
+            const int cpt = A32 ? 4 : 2, nunit = cols / cpt;
+            int parts = CB_NT / nunit;
+            if (parts > 3) parts = 3;
+            const int pt = tid / nunit, un = tid - pt * nunit;
+            if (pt < parts) {
+                const int per = (n + parts - 1) / parts;
+                const int i0 = pt * per, i1 = (i0 + per < n) ? i0 + per : n;
+                double w[4][8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) w[c][o] = 0.0;
+                const size_t ac = (size_t)cpt * un;
+#pragma unroll 4
+                for (int i = i0; i < i1; ++i) {
+                    double a[4];
+                    if (A32) {
+                        const float4 af = *reinterpret_cast<const float4*>(A32 + ac + (size_t)i * cols);
+                        a[0] = (double)af.x; a[1] = (double)af.y; a[2] = (double)af.z; a[3] = (double)af.w;
+                    } else {
+                        const double2 ad = *reinterpret_cast<const double2*>(A + ac + (size_t)i * cols);
+                        a[0] = ad.x; a[1] = ad.y; a[2] = 0.0; a[3] = 0.0;
+                    }
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+                        if (o < nrhs) {
+                            const double al = Bs[o * np + i];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (c < cpt) w[c][o] = fma(a[c], al, w[c][o]);
+                        }
+                }
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o < nrhs) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < cpt) part[(pt * 8 + o) * cols + cpt * un + c] = w[c][o];
+                    }
+            }
+            __syncthreads();
+            for (int e = tid; e < nrhs * cols; e += CB_NT) {
+                const int o = e / cols, c = e - o * cols;
+                double v = part[o * cols + c];
+                for (int q = 1; q < parts; ++q) v += part[(q * 8 + o) * cols + c];
+                sp.W_out[((size_t)g * nrhs + o) * cols + c] = v;
+            }
+        } else {
+            for (int c = tid; c < cols; c += CB_NT) {
+                double w[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) w[o] = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    const double a = A32 ? (double)A32[(size_t)i * cols + c] : A[(size_t)i * cols + c];
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+                        if (o < nrhs) w[o] = fma(a, Bs[o * np + i], w[o]);
+                }
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o < nrhs) sp.W_out[((size_t)g * nrhs + o) * cols + c] = w[o];
+            }
+        }
+    } else {
+        for (int e = tid; e < nrhs * cols; e += CB_NT) {
+            const int o = e / cols, c = e % cols;
+            sp.W_out[((size_t)g * nrhs + o) * cols + c] = Bs[o * np + c];
+        }
+    }
+    if (tid == 0) sp.status[g] = sh_bad;
+}
+
+static int chol_big_parts(int cols, bool f32) {          // 0 = the partial-sums pass does not apply
+    const int cpt = f32 ? 4 : 2;
+    if (cols % cpt) return 0;
+    const int nunit = cols / cpt;
+    if (nunit > CB_NT) return 0;
+    const int parts = CB_NT / nunit > 3 ? 3 : CB_NT / nunit;
+    return ((size_t)8 * CB_NMAX * 8 + (size_t)parts * 8 * cols * 8 <= 140 * 1024) ? parts : 0;
+}
+static size_t chol_big_lds_bytes(int cols, bool f32) {
+    const size_t gram = 2 * (size_t)CB_KC * (CB_NMAX + 4) * 8;
+    size_t tail = (size_t)CB_NMAX * CB_PLD * 8;
+    const size_t pp = (size_t)chol_big_parts(cols, f32) * 8 * cols * 8;
+    if (pp > tail) tail = pp;
+    tail += (size_t)8 * CB_NMAX * 8;
+    return gram > tail ? gram : tail;
+}
+
+int launch_readout_chol_big(const double* E, const float* E32, const double* D, int n_groups, int T, int transient,
+                            int cols, int n_out, const double* t_scale, const double* t_shift,
+                            double* W_out, int* status, void* workspace, hipStream_t stream) {
+    SolveParams sp;
+    const int rows = T - transient;
+    const int n = rows < cols ? rows : cols;
+    if (n > CB_NMAX || n_out > 8) return -1;
+    const size_t lds = chol_big_lds_bytes(cols, E32 != nullptr);
+    sp.part_ok = chol_big_parts(cols, E32 != nullptr) > 0 ? 1 : 0;
+    sp.E = E; sp.E32 = E32; sp.D = D; sp.n_groups = n_groups; sp.T = T; sp.transient = transient;
+    sp.cols = cols; sp.n_out = n_out; sp.t_scale = t_scale; sp.t_shift = t_shift;
+    sp.W_out = W_out; sp.status = status;
+    sp.work = reinterpret_cast<double*>(workspace); sp.work_stride = chol_big_work_doubles(n);
+    sp.wide = rows < cols; sp.m = sp.wide ? cols : rows; sp.n = n; sp.skip = 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(readout_chol_big_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(readout_chol_big_kernel, dim3(n_groups), dim3(CB_NT), lds, stream, sp);
     return (int)hipGetLastError();
 }
 

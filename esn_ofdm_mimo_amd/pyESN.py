@@ -149,6 +149,7 @@ class ESN:
         bank.set_readout(W_out)
         self.fit_status = int(status[0].item())
         self.W_out = W_out[0].cpu().numpy()
+        bank.raise_if_cluster_timed_out()
         ext = E[0]
         self.laststate = ext[-1, :self.n_reservoir].cpu().numpy()
         self.lastinput = inputs[-1, :]
@@ -187,7 +188,9 @@ class ESN:
             y = bank.predict(inputs[None], frames_per_group=1, transient=transient, precision=precision or "f64",
                              x0=x0, y0=y0, noise_mode="tensor" if self.noise else "none",
                              noise_u=noise_u[None])
-            return y[0].cpu().numpy()
+            y = y[0].cpu().numpy()
+            bank.raise_if_cluster_timed_out()
+            return y
         if inputs.ndim != 3:
             raise ValueError("predict takes [T, n_in] or a batch [B, T, n_in]")
         b = inputs.shape[0]

@@ -88,6 +88,7 @@ int esn_abi_version(void);
  *                   (esn_recur_rs.hip; an experiment kept for A/B runs, compiled only into ESN_WITH_RS=1 builds:
  *                   the product library answers -3) instead of the skewed LDS-state kernel
  *   "big_gemm"      "0" = N_res > 1024 predict on the persistent kernel even when a workspace is given
+ *   "cluster"       "0" = a single float64 sequence on the vector-ALU kernel even when a workspace is given
  * Returns 0, or -1 for an unknown key. */
 int esn_debug_set(const char* key, const char* value);
 
@@ -137,10 +138,14 @@ int esn_pack_readout(int precision, const esn_shape_t* shape, int n_groups,
  *                 output (continuation=True: laststate/lastoutput, :234-237) or NULL (zeros)
  *   noise_u       [B][T][n_res] uniforms when noise_mode == ESN_NOISE_TENSOR
  *   Y             [B][T-transient][n_out], unscaled (:255); 16-byte aligned (rows are written as 16-byte pairs)
- *   workspace     device scratch of esn_predict_workspace_bytes(...) bytes, or NULL.  Only reservoirs
- *                 beyond 1024 units in fp16/bf16 use it (there the recurrence runs as one tiled GEMM launch
- *                 per timestep with the state images in the workspace); with NULL every shape runs on the
- *                 persistent kernels.  No allocation happens inside the call either way.
+ *   workspace     device scratch of esn_predict_workspace_bytes(...) bytes, or NULL.  Two shapes use it:
+ *                 reservoirs beyond 1024 units in fp16/bf16 (the recurrence runs as one tiled GEMM launch
+ *                 per timestep with the state images in the workspace), and ONE float64 sequence (n_frames = 1:
+ *                 the reference's own call pattern) -- the matrix then stays resident in the LDS of a cluster of
+ *                 co-resident workgroups that exchange the state through the workspace every step
+ *                 (esn_recur_cluster.hip); its last 64 bytes hold an error word that is non-zero if a workgroup
+ *                 timed out waiting for the others (the outputs are then invalid).  With NULL every shape runs on
+ *                 the persistent kernels.  No allocation happens inside the call either way.
  */
 size_t esn_predict_workspace_bytes(int precision, const esn_shape_t* shape, int n_frames, int frames_per_group);
 int esn_predict_batch(int precision, const esn_shape_t* shape,
@@ -206,20 +211,23 @@ int esn_readout_solve_batch(const double* E, const double* D, int n_groups, int 
                             const double* t_scale, const double* t_shift,
                             double* W_out, int* status, void* workspace, void* stream);
 
-/* Same contract, normal equations in float64 with the Gram matrix (min(rows, cols) <= 128) and its
- * Cholesky factor resident in LDS -- the fast path for well-conditioned batched fits (with the
- * model's state noise cond(E) ~ 1e3, error ~ cond^2 eps ~ 1e-10).  status[g] = 1 when a pivot was
- * rejected: re-solve that group with esn_readout_solve_batch.  Needs n_out <= 8; returns -2 when
- * the shape does not fit.  No workspace. */
+/* Same contract, normal equations in float64 on the float64 matrix pipe -- the fast path for well-conditioned
+ * batched fits (with the model's state noise cond(E) ~ 1e3, error ~ cond^2 eps ~ 1e-10).  min(rows, cols) <= 128:
+ * Gram matrix and Cholesky factor resident in LDS, no workspace (NULL).  129 .. 512 (4x8 at N = 512: 512 x 528;
+ * N_res = 300: 512 x 316): Gram matrix / factor column-major in the caller's workspace of
+ * esn_readout_chol_workspace_bytes(...) bytes (16-byte aligned, as E), left-looking blocked factorisation.
+ * status[g] = 1 when a pivot was rejected: re-solve that group with esn_readout_solve_batch.  Needs n_out <= 8;
+ * returns -2 when the shape is not served. */
+size_t esn_readout_chol_workspace_bytes(int n_groups, int rows, int cols);
 int esn_readout_solve_chol_batch(const double* E, const double* D, int n_groups, int T,
                                  int transient, int cols, int n_out,
                                  const double* t_scale, const double* t_shift,
-                                 double* W_out, int* status, void* stream);
+                                 double* W_out, int* status, void* workspace, size_t workspace_bytes, void* stream);
 /* ... with E as written by esn_harvest_batch_f32 (arithmetic still float64). */
 int esn_readout_solve_chol_batch_f32(const float* E, const double* D, int n_groups, int T,
                                      int transient, int cols, int n_out,
                                      const double* t_scale, const double* t_shift,
-                                     double* W_out, int* status, void* stream);
+                                     double* W_out, int* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused detector tail: Y [B][N][2 N_t] time-domain ESN outputs
  * -> (1/N) FFT_N / sqrt(Pi[group]) -> nearest unit-power square-QAM point ->

@@ -294,7 +294,10 @@ def test_per_group_reservoirs(amd):
 
 
 @pytest.mark.parametrize("method,tol", [("qr", 1e-9), ("chol", 1e-7)])
-@pytest.mark.parametrize("rows,cols", [(128, 528), (40, 40), (512, 104), (300, 90)])
+@pytest.mark.parametrize("rows,cols", [(128, 528), (40, 40), (512, 104), (300, 90),
+                                       # Gram dimension beyond 128: the workspace (out-of-LDS) Cholesky kernel --
+                                       # 4x8 at N = 512 (512 x 528), N_res = 300 at N = 512 (512 x 316), ragged tiles
+                                       (512, 528), (512, 316), (200, 700), (130, 131), (333, 150)])
 def test_readout_solve_vs_pinv(amd, rows, cols, method, tol):
     _, _, batched = amd
     rs = np.random.RandomState(rows + cols)
@@ -333,6 +336,28 @@ def test_chol_flags_rank_deficiency_and_qr_repairs(amd):
         assert rel_err(W[g].cpu().numpy(), (np.linalg.pinv(E[g]) @ D[g]).T) < 1e-7
     # flagged group after QR: reproduces the teacher on every row (the duplicate included)
     assert rel_err(E[1] @ W[1].cpu().numpy().T, D[1]) < 1e-6
+
+
+def test_big_chol_float32_states_and_rank_flag(amd):
+    """The workspace Cholesky kernel on float32 extended states (the batched fit's storage) and its pivot flag."""
+    import torch
+    _, _, batched = amd
+    rs = np.random.RandomState(77)
+    G, rows, cols, n_out = 4, 256, 528, 8
+    bank = batched.ReservoirBank(cols - 2, n_out, 2, np.zeros((2, 2)), np.zeros((2, cols - 2)), np.zeros((2, n_out)))
+    E = rs.randn(G, rows, cols).astype(np.float32)
+    D = rs.randn(G, rows, n_out)
+    E[2, 100] = E[2, 17]
+    D[2, 100] = D[2, 17]
+    W, status = bank.solve(torch.as_tensor(E, device="cuda"), D, 0, method="chol")
+    st = status.cpu().numpy()
+    assert list(st) == [0, 0, 1, 0]
+    for g in (0, 1, 3):
+        want = (np.linalg.pinv(E[g].astype(np.float64)) @ D[g]).T
+        assert rel_err(W[g].cpu().numpy(), want) < 1e-7
+    n = bank.resolve_failed(torch.as_tensor(E, device="cuda").double(), D, 0, W, status)
+    assert n == 1
+    assert rel_err(E[2].astype(np.float64) @ W[2].cpu().numpy().T, D[2]) < 1e-6
 
 
 def test_detect_count_vs_oracle(amd, golden):

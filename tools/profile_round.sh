@@ -6,9 +6,10 @@ set -e -o pipefail
 TAG=${1:-r02}; PREC=${2:-f16}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+PY=$(python3 -c 'import sys; print(sys.executable)')   # the real interpreter: no exec hop under the profiler
 mkdir -p gpurun_out profiles
 rm -rf gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --precision $PREC --steps 5 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_${TAG}.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- "$PY" bench.py --precision $PREC --steps 5 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_${TAG}.err
 STATS=$(find gpurun_out/prof_$TAG -name '*kernel_stats.csv' | head -1)
 python3 tools/trim_kernel_stats.py "$STATS" profiles/${TAG}_bench_${PREC}_kernel_stats.csv 14
 cp gpurun_out/prof_${TAG}_bench.json profiles/${TAG}_bench_${PREC}_profiled.json
