@@ -57,7 +57,7 @@ SIGNATURES = {
     "esn_gen_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  _dp, _dp, C.c_double, _dp, _vp, _dp, C.c_uint64, C.c_uint64, _vp, _dp, _dp, _vp]),
     "esn_channel_estimate": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
-                                       C.c_double, _vp, _dp, _dp, _vp]),
+                                       C.c_double, _vp, _dp, C.c_int, _dp, _vp]),
     "esn_mmse_detect_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
                                         C.c_double, _dp, _dp, _vp, _vp, _vp, _dp, _vp]),
     "esn_zf_detect_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,

@@ -586,7 +586,7 @@ static int pow2_log(int n) { int l = 0; while ((1 << l) < n) ++l; return ((1 << 
 
 int esn_channel_estimate(int n_blocks, int n_sub, int cp, int n_t, int n_r, int isi, int bits_per_sym,
                          const double* p_i, double no, const uint8_t* pilot_bits, const double* y_ls_cp,
-                         double* H, void* stream) {
+                         int ls_only, double* H, void* stream) {
     if (!p_i || !pilot_bits || !y_ls_cp || !H) return fail(-1, "esn_channel_estimate: null pointer");
     const int l2 = pow2_log(n_sub);
     if (l2 < 1 || n_sub > 2048) return fail(-1, "esn_channel_estimate: N=%d must be a power of two in [2, 2048]", n_sub);
@@ -596,6 +596,7 @@ int esn_channel_estimate(int n_blocks, int n_sub, int cp, int n_t, int n_r, int 
     ChanEstParams c;
     c.n_blocks = n_blocks; c.n_sub = n_sub; c.log2n = l2; c.cp = cp; c.n_t = n_t; c.n_r = n_r; c.isi = isi;
     c.m = bits_per_sym; c.p_i = p_i; c.no = no; c.pilot_bits = pilot_bits; c.y_ls_cp = y_ls_cp; c.H = H;
+    c.ls_only = ls_only ? 1 : 0;
     return hip_fail(launch_channel_estimate(c, (hipStream_t)stream), "esn_channel_estimate");
 }
 

@@ -88,6 +88,14 @@ __global__ __launch_bounds__(256) void channel_estimate_kernel(ChanEstParams cp)
             full[k] = make_double2(lo.x + w * (hi.x - lo.x), lo.y + w * (hi.y - lo.y));
         }
         __syncthreads();
+        if (cp.ls_only) {      // H_LS of the block-fading drivers: the interpolated LS estimate as is (:321-333)
+            for (int k = tid; k < N; k += nth) {
+                double* ho = cp.H + ((((size_t)blk * N + k) * n_r + rx) * n_t + tx) * 2;
+                ho[0] = full[k].x; ho[1] = full[k].y;
+            }
+            __syncthreads();
+            continue;
+        }
         // c_LS[j] = (1/N) sum_k full[k] e^{+2 pi i jk/N}, j < isi; then shrink
         if (tid < isi) {
             double ar = 0.0, ai = 0.0;

@@ -107,6 +107,7 @@ struct FrameGenParams {
 // baseline equaliser (esn_baseline.hip)
 struct ChanEstParams {
     int n_blocks, n_sub, log2n, cp, n_t, n_r, isi, m;
+    int ls_only;                 // 1: stop at the interpolated LS estimate (H_LS), no time-domain MMSE refinement
     const double* p_i; double no;
     const uint8_t* pilot_bits;   // [G][N*m][n_t]
     const double* y_ls_cp;       // complex [G][T][n_r]

@@ -178,21 +178,34 @@ class FrameSource:
         return out
 
     # ---- baseline equaliser ------------------------------------------------------
-    def estimate_channel(self, pilot_bits, pilot_y_ls, ebno_db):
-        """LS + time-domain MMSE channel estimate H [G, N, n_r, n_t] (driver:358-382)."""
+    def estimate_channel(self, pilot_bits, pilot_y_ls, ebno_db, ls_only=False):
+        """LS + time-domain MMSE channel estimate H [G, N, n_r, n_t] (driver:358-382); ls_only: the interpolated
+        LS estimate H_LS of the block-fading drivers' LS-ZF detector (OFDM_MIMO_2-2_NBF_LDPC.py:321-333)."""
         torch, p = self.torch, self.p
         g = pilot_bits.shape[0]
         with torch.cuda.device(self.device):
             p_i = torch.full((g,), p.p_i(ebno_db), dtype=torch.float64, device=self.device)
             H = torch.empty((g, p.n_sub, p.n_r, p.n_t), dtype=torch.complex128, device=self.device)
             check(self.lib.esn_channel_estimate(g, p.n_sub, p.cp, p.n_t, p.n_r, p.isi, p.m, ptr(p_i), p.no,
-                                                ptr(pilot_bits.contiguous()), ptr(pilot_y_ls.contiguous()), ptr(H),
-                                                _lib.stream_handle()), "esn_channel_estimate")
+                                                ptr(pilot_bits.contiguous()), ptr(pilot_y_ls.contiguous()),
+                                                1 if ls_only else 0, ptr(H), _lib.stream_handle()),
+                  "esn_channel_estimate")
+        return H
+
+    def true_channel(self, taps):
+        """H_true [G, N, n_r, n_t] = FFT_N of the zero-padded taps (OFDM_MIMO_2-2_NBF_LDPC.py:273-279)."""
+        torch, p = self.torch, self.p
+        g = taps.shape[0]
+        with torch.cuda.device(self.device):
+            H = torch.empty((g, p.n_sub, p.n_r, p.n_t), dtype=torch.complex128, device=self.device)
+            check(self.lib.esn_taps_to_freq(g, p.n_sub, p.n_t, p.n_r, p.isi, ptr(taps.contiguous()), ptr(H),
+                                            _lib.stream_handle()), "esn_taps_to_freq")
         return H
 
     def mmse_detect_count(self, H, data_y, data_bits, frames_per_block, ebno_db, err=None, bits=None,
-                          want_xhat=False):
-        """Per-subcarrier MMSE detector + error counters (driver:444-456)."""
+                          want_xhat=False, zf=False):
+        """Per-subcarrier MMSE detector + error counters (driver:444-456); zf=True: equalize_zf (driver:34-39),
+        LS-ZF with an estimated H, Perfect-ZF with `true_channel` (OFDM_MIMO_2-2_NBF_LDPC.py:450-460)."""
         torch, p = self.torch, self.p
         g, b = H.shape[0], data_y.shape[0]
         with torch.cuda.device(self.device):
@@ -202,10 +215,16 @@ class FrameSource:
             if bits is None:
                 bits = torch.zeros(g, dtype=torch.int64, device=self.device)
             xh = torch.empty((b, p.n_sub, p.n_t), dtype=torch.complex128, device=self.device) if want_xhat else None
-            check(self.lib.esn_mmse_detect_count(b, int(frames_per_block), p.n_sub, p.cp, p.n_t, p.n_r, p.m,
-                                                 ptr(p_i), p.no, ptr(H), ptr(data_y.contiguous()),
-                                                 ptr(data_bits.contiguous()), ptr(err), ptr(bits), ptr(xh),
-                                                 _lib.stream_handle()), "esn_mmse_detect_count")
+            if zf:
+                check(self.lib.esn_zf_detect_count(b, int(frames_per_block), p.n_sub, p.cp, p.n_t, p.n_r, p.m,
+                                                   ptr(p_i), ptr(H), ptr(data_y.contiguous()),
+                                                   ptr(data_bits.contiguous()), ptr(err), ptr(bits), ptr(xh),
+                                                   _lib.stream_handle()), "esn_zf_detect_count")
+            else:
+                check(self.lib.esn_mmse_detect_count(b, int(frames_per_block), p.n_sub, p.cp, p.n_t, p.n_r, p.m,
+                                                     ptr(p_i), p.no, ptr(H), ptr(data_y.contiguous()),
+                                                     ptr(data_bits.contiguous()), ptr(err), ptr(bits), ptr(xh),
+                                                     _lib.stream_handle()), "esn_mmse_detect_count")
         return (err, bits, xh) if want_xhat else (err, bits)
 
 
@@ -437,4 +456,67 @@ def coded_ber_point(sweep, code, ebno_db, snr_idx, n_blocks, frames_per_block=No
         out[name + "_coded"] = float(err.sum()) / max(float(nb.sum()), 1.0)
         out["a_" + name.lower()] = a.cpu().numpy()
         out["b_" + name.lower()] = b.cpu().numpy()
+    return out
+
+
+def block_fading_point(sweep, code, ebno_db, snr_idx, n_blocks, fixed_sweep=None, decode_every=4, llr_scale=1.5,
+                       seed=0):
+    """One Eb/No point of the block-fading drivers' comparison (OFDM_{SISO,SIMO_1-2,MIMO_2-2}_NBF_LDPC.py /
+    Demo_MIMO_4x8_ChannelRank_..._fast.py :266-521), batched on the device: per coherence block one pilot and
+    L - 1 LDPC-coded data symbols (the pilot symbol carries no data here, :387); detectors ESN (SNR-matched),
+    ESN trained at a fixed Eb/No (`fixed_sweep`: a DetectorSweep built with train_ebno=12), LS-ZF,
+    MMSE and Perfect-ZF (:450-460); uncoded BER over every data symbol, coded BER on every `decode_every`-th
+    symbol of the run (kk % 4 == 1, :202,389) with the drivers' uncalibrated LLRs: per-stream decision-directed
+    sigma^2, x LLR_SCALE 1.5, clip +-20 (:478-485).  Returns the reference's holder names (BER_* / BERC_*)."""
+    torch, p, src = sweep.torch, sweep.p, sweep.src
+    L = p.coherence_symbols
+    F, G = L - 1, n_blocks
+    gen = torch.Generator(device=sweep.device)
+    gen.manual_seed((seed * 1000003 + snr_idx * 7919 + 4242) % (2 ** 63 - 1))
+    u = torch.randint(0, 2, (G * F, p.n_t, code.k), generator=gen, device=sweep.device, dtype=torch.uint8)
+    tx_bits = code.encode(u, p.n_t)
+    taps = src.taps(G, snr_idx, 0)
+    pbits, px, py = src.frames(taps, 1, ebno_db, snr_idx, 0, 0, want_x=True)
+    _, _, py_ls = src.frames(taps, 1, ebno_db, snr_idx, 0, 0, ls_pattern=True)
+    _, _, dy = src.frames(taps, F, ebno_db, snr_idx, 0, 1, bits_in=tx_bits)
+    xhat = {}
+    err = {}
+
+    def esn_leg(sw, name, pilot_y, pilot_x, scale_ebno):
+        sw.set_snr(ebno_db, G)
+        if scale_ebno != ebno_db:
+            ones_in = torch.ones((G, sw.n_in), dtype=torch.float64, device=sw.device)
+            sw.bank.in_scale = ones_in * p.input_scaling(scale_ebno)
+        E = sw.train(pilot_y, pilot_x, seed=sw.stream_seed(snr_idx, 0) + seed)
+        sw.repair_fit(E)
+        y = sw.bank.predict(_view_real(dy), F, T=p.t_frame + p.delay, transient=p.forget, precision=sw.precision,
+                            noise_mode="counter", seed=sw.stream_seed(snr_idx, 1) + seed)
+        e, nb, xh = sw.bank.detect_count(y, tx_bits, sw.p_i, F, p.n_sub, p.n_t, p.m, want_xhat=True)
+        xhat[name] = torch.view_as_complex(xh.view(G * F, p.n_sub, p.n_t, 2).contiguous())
+        err[name] = (e, nb)
+
+    esn_leg(sweep, "ESN_matched", py, px, ebno_db)
+    if fixed_sweep is not None:
+        t_eb = fixed_sweep.train_ebno
+        _, px_f, py_f = src.frames(taps, 1, t_eb, snr_idx, 0, 0, want_x=True)     # same pilot bits at the fixed power
+        esn_leg(fixed_sweep, "ESN_trainFixed", py_f, px_f, t_eb)
+    H_ls = src.estimate_channel(pbits, py_ls, ebno_db, ls_only=True)
+    H_mmse = src.estimate_channel(pbits, py_ls, ebno_db)
+    H_true = src.true_channel(taps)
+    for name, H, zf in (("LS_ZF", H_ls, True), ("MMSE", H_mmse, False), ("PerfectZF", H_true, True)):
+        e, nb, xh = src.mmse_detect_count(H, dy, tx_bits, F, ebno_db, want_xhat=True, zf=zf)
+        xhat[name], err[name] = xh, (e, nb)
+    out = {"BER_" + k: float(v[0].sum()) / float(v[1].sum()) for k, v in err.items()}
+    # coded leg: symbol kk (1-based over the run; block b holds kk = L b + 1 (pilot) .. L b + L) decodes iff kk % every == 1
+    kk = (torch.arange(G, device=sweep.device)[:, None] * L + 2 + torch.arange(F, device=sweep.device)[None, :]).reshape(-1)
+    sel = torch.nonzero((kk % decode_every) == 1).flatten()
+    a = torch.full((p.m,), -float(llr_scale), dtype=torch.float64, device=sweep.device)   # -(a llr + b) = scale * llr
+    b = torch.zeros(p.m, dtype=torch.float64, device=sweep.device)
+    for name, xh in xhat.items():
+        xs = xh[sel]                                                           # [S, N, n_t]
+        per_stream = xs.permute(0, 2, 1).reshape(-1, p.n_sub, 1).contiguous()  # sigma^2 per (frame, tx) column (:479)
+        llr, _ = code.llrs(per_stream, p.m)                                    # [S n_t, 1, N m]
+        e, nb = code.decode_count(llr.view(xs.shape[0], p.n_t, -1), a, b, u[sel], max(1, xs.shape[0] * p.n_t), p.m)
+        out["BERC_" + name] = float(e.sum()) / max(float(nb.sum()), 1.0)
+    out["decoded_symbols"] = int(sel.numel())
     return out

@@ -270,7 +270,9 @@ int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_
  * esn_channel_estimate   pilot_bits [G][N*m][n_t], y_ls_cp complex [G][T][n_r] (received sparse LS
  *                        pilot) -> H complex [G][N][n_r][n_t]: LS at sc = tx + n_t i, linear
  *                        inter/extrapolation, IFFT -> isi taps, diagonal MMSE shrinkage, DFT
- *                        (Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:358-382).
+ *                        (Demo_MIMO_4x8_Sionna_CDL_ESN_v2.py:358-382); ls_only = 1 stops at the interpolated LS
+ *                        estimate, the H_LS the block-fading drivers feed their LS-ZF detector
+ *                        (OFDM_MIMO_2-2_NBF_LDPC.py:321-333,457).
  * esn_mmse_detect_count  y_cp complex [B][T][n_r] -> X = (H^H H + No/Pi I)^-1 H^H Y / sqrt(Pi) per
  *                        subcarrier (:40-45, :444-448), hard decision + error count as in
  *                        esn_detect_count; n_t <= 4.  X_hat complex [B][N][n_t] optional.
@@ -280,7 +282,7 @@ int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_
  *                        = FFT_N of the zero-padded impulse response (H_true, OFDM_MIMO_2-2_NBF_LDPC.py:273-279). */
 int esn_channel_estimate(int n_blocks, int n_sub, int cp, int n_t, int n_r, int isi, int bits_per_sym,
                          const double* p_i, double no, const uint8_t* pilot_bits,
-                         const double* y_ls_cp, double* H, void* stream);
+                         const double* y_ls_cp, int ls_only, double* H, void* stream);
 int esn_mmse_detect_count(int n_frames, int frames_per_group, int n_sub, int cp, int n_t, int n_r,
                           int bits_per_sym, const double* p_i, double no, const double* H,
                           const double* y_cp, const uint8_t* tx_bits,

@@ -69,9 +69,10 @@ def pilot_frames(cfg: LinkConfig, ebno_db, taps, rng):
     return dict(bits=bits, X_p=x_p, X_LS=x_ls, x_cp=x_cp, y_cp=y, y_ls_cp=y_ls)
 
 
-def estimate_channel(cfg: LinkConfig, ebno_db, x_ls, y_ls_cp):
+def estimate_channel(cfg: LinkConfig, ebno_db, x_ls, y_ls_cp, ls_only=False):
     """H_MMSE [N, n_r, n_t]: LS at every n_t-th subcarrier, linear interpolation with
-    extrapolation, IFFT, truncate to isi taps, diagonal MMSE shrinkage, FFT (driver:358-382)."""
+    extrapolation, IFFT, truncate to isi taps, diagonal MMSE shrinkage, FFT (driver:358-382).
+    ls_only: the interpolated LS estimate H_LS itself (OFDM_MIMO_2-2_NBF_LDPC.py:321-333, fed to LS-ZF)."""
     n, p_i = cfg.n_sub, cfg.p_i(ebno_db)
     y_ls = (1.0 / n) * np.fft.fft(y_ls_cp[cfg.cp:], axis=0)
     r_h = np.diag(isi_magnitude(cfg)[:cfg.isi])
@@ -83,6 +84,9 @@ def estimate_channel(cfg: LinkConfig, ebno_db, x_ls, y_ls_cp):
             hls = y_ls[sc, nr] / (x_ls[sc, tx] * math.sqrt(p_i) + 1e-12)
             full = interpolate.interp1d(sc, hls, kind="linear", bounds_error=False,
                                         fill_value="extrapolate")(np.arange(n))
+            if ls_only:
+                h[:, nr, tx] = full
+                continue
             c_ls = np.fft.ifft(full)[:cfg.isi]
             c_mmse = np.linalg.solve(scaler * np.linalg.inv(r_h) + np.eye(cfg.isi), c_ls)
             h[:, nr, tx] = np.fft.fft(np.r_[c_mmse, np.zeros(n - cfg.isi)])

@@ -88,7 +88,7 @@ class OracleESN:
                  spectral_radius=0.95, sparsity=0, noise=0.001,
                  input_shift=None, input_scaling=None, teacher_forcing=True,
                  feedback_scaling=None, teacher_scaling=None,
-                 teacher_shift=None, random_state=None):
+                 teacher_shift=None, random_state=None, weights=None):
         self.n_inputs, self.n_outputs, self.n_reservoir = n_inputs, n_outputs, n_reservoir
         self.spectral_radius, self.sparsity, self.noise = spectral_radius, sparsity, noise
         self.input_shift = broadcast_arg(input_shift, n_inputs)
@@ -105,8 +105,13 @@ class OracleESN:
                 raise Exception("Invalid seed: " + str(e))
         else:
             self.rng = np.random.mtrand._rand
-        self.W, self.W_in, self.W_feedb = draw_weights(
-            self.rng, n_inputs, n_outputs, n_reservoir, spectral_radius, sparsity)
+        if weights is not None:
+            # (test convenience, not in the reference: reuse weights drawn once -- the eigvals of a 2048 x 2048
+            #  matrix takes 10-40 s of host time per construction)
+            self.W, self.W_in, self.W_feedb = weights
+        else:
+            self.W, self.W_in, self.W_feedb = draw_weights(
+                self.rng, n_inputs, n_outputs, n_reservoir, spectral_radius, sparsity)
 
     # a4 ------------------------------------------------------------------
     def scale_inputs(self, u):

@@ -72,8 +72,9 @@ def test_big_gemm_path_matches_persistent_kernel(mods, n_res, n_in, n_out, G, F,
         for b in (0, F - 1, F, B - 1):
             grp = b // F
             o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[grp], input_shift=in_shift[grp],
-                             teacher_scaling=t_scale[grp], teacher_shift=t_shift[grp], random_state=1)
-            o.W, o.W_in, o.W_feedb, o.W_out = w, w_in, w_fb, w_out[grp]
+                             teacher_scaling=t_scale[grp], teacher_shift=t_shift[grp], random_state=1,
+                             weights=(w, w_in, w_fb))
+            o.W_out = w_out[grp]
             o.laststate, o.lastoutput = x0[grp], y0[grp]
             want = o.predict(np.vstack([u[b], np.zeros((t - t_in, n_in))]), tr, continuation=True)
             assert rel_err(big[b], want) < (2e-2 if precision == "f16" else 1e-1), (b, rel_err(big[b], want))
@@ -134,7 +135,6 @@ def test_big_gemm_harvest_matches_persistent_kernel(mods, n_res, n_in, n_out, G,
     if noise == 0.0:
         for g in (0, G - 1):
             o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, input_scaling=in_scale[g], input_shift=in_shift[g],
-                             teacher_scaling=t_scale[g], teacher_shift=t_shift[g], random_state=1)
-            o.W, o.W_in, o.W_feedb = w, w_in, w_fb
+                             teacher_scaling=t_scale[g], teacher_shift=t_shift[g], random_state=1, weights=(w, w_in, w_fb))
             o.fit(u[g], d[g], 2)
             assert rel_err(big[g], o._ext_states) < (2e-2 if precision == "f16" else 1e-1)

@@ -77,8 +77,8 @@ def test_cluster_kernel_matches_vector_kernel_and_oracle(mods, n_res, n_in, n_ou
         assert rel_err(a, b) < 1e-11, rel_err(a, b)
     if noise_mode != "counter":
         o = eo.OracleESN(n_in, n_out, n_res, noise=noise, input_scaling=in_scale[0], input_shift=in_shift[0],
-                         teacher_scaling=t_scale[0], teacher_shift=t_shift[0], random_state=1)
-        o.W, o.W_in, o.W_feedb, o.W_out = w, w_in, w_fb, w_out[0]
+                         teacher_scaling=t_scale[0], teacher_shift=t_shift[0], random_state=1, weights=(w, w_in, w_fb))
+        o.W_out = w_out[0]
         o.laststate, o.lastoutput = x0[0], y0[0]
         if noise_mode == "tensor":
             o.rng = ReplayRng(nz_p[0])
