@@ -44,6 +44,18 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, double& z0, d
     z0 = rr * cs; z1 = rr * sn;
 }
 
+// the same from the float32 hardware transcendentals (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32 take the angle
+// in revolutions): ~10 instructions instead of ~150 of float64 library code per pair.  Relative accuracy ~1e-6 --
+// a noise sample needs the right DISTRIBUTION, not float64 digits; |z| reaches 6.7 (u1 >= 2^-33).  The AWGN of
+// 1 080 samples per frame was two thirds of the generator's instructions in float64.
+__device__ __forceinline__ void box_muller_fast(uint32_t a, uint32_t b, double& z0, double& z1) {
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);          // 24 bits: exact in float32, never 0 or 1
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    const float rr = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), log2 based
+    z0 = (double)(rr * __builtin_amdgcn_cosf(u2));
+    z1 = (double)(rr * __builtin_amdgcn_sinf(u2));
+}
+
 enum { PURPOSE_BITS = 1, PURPOSE_NOISE = 2, PURPOSE_TAPS = 3 };
 
 __global__ void gen_taps_kernel(TapParams tp) {
@@ -121,17 +133,11 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
         tw[k] = make_double2(cs, sn);
     }
     // ---- bits -> constellation point (index = sum_b bit_b 2^b = i*side + j; Re = pam[i], Im = pam[j])
-    for (int e = tid; e < N * n_t; e += nth) {
+    // random payload: ONE Philox call per 128 bits = 4 (32 / m) symbols (v_mul_hi_u32 is a quarter-rate instruction:
+    // a call per symbol was 512 calls per frame for 2 048 bits); thread t owns call t
+    const int spw = 32 / m, spc = 4 * spw;                   // symbols per word / per call
+    auto place = [&](int e, uint32_t idx) {
         const int sc = e / n_t, tx = e % n_t;
-        uint32_t idx = 0;
-        if (fp.bits_in) {
-            for (int b = 0; b < m; ++b)
-                idx |= (uint32_t)(fp.bits_in[((size_t)frame * N * m + (size_t)sc * m + b) * n_t + tx] & 1) << b;
-        } else {
-            uint32_t w[4];
-            ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_BITS, (uint32_t)e, w);
-            idx = w[0] & ((1u << m) - 1);
-        }
         for (int b = 0; b < m; ++b)
             fp.bits[((size_t)frame * N * m + (size_t)sc * m + b) * n_t + tx] = (uint8_t)((idx >> b) & 1);
         const int pi_ = (int)(idx / side), pj = (int)(idx % side);
@@ -139,6 +145,26 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
         const bool on = !fp.ls_pattern || (sc % n_t == tx);
         X[(size_t)tx * N + rv] = on ? make_double2((2.0 * pi_ - (side - 1)) / norm, (2.0 * pj - (side - 1)) / norm)
                                     : make_double2(0.0, 0.0);
+    };
+    if (fp.bits_in) {
+        for (int e = tid; e < N * n_t; e += nth) {
+            const int sc = e / n_t, tx = e % n_t;
+            uint32_t idx = 0;
+            for (int b = 0; b < m; ++b)
+                idx |= (uint32_t)(fp.bits_in[((size_t)frame * N * m + (size_t)sc * m + b) * n_t + tx] & 1) << b;
+            place(e, idx);
+        }
+    } else {
+        for (int call = tid; call * spc < N * n_t; call += nth) {
+            uint32_t w[4];
+            ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_BITS, (uint32_t)call, w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                for (int j = 0; j < spw; ++j) {
+                    const int e = call * spc + q * spw + j;
+                    if (e < N * n_t) place(e, (w[q] >> (j * m)) & ((1u << m) - 1));
+                }
+        }
     }
     __syncthreads();
     // ---- x = N * ifft(X): un-normalised inverse DFT, radix-2 DIT on bit-reversed input, per tx
@@ -232,21 +258,30 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
         };
         if (isi == 8) channel(std::integral_constant<int, 8>{}); else channel(std::integral_constant<int, 0>{});
         if (!live) continue;
+        // AWGN: one Philox call per PAIR of receive antennas (4 words = two complex samples), counter (t, rx / 2)
 #pragma unroll
-        for (int q = 0; q < GEN_RXG; ++q) {
+        for (int q = 0; q < GEN_RXG; q += 2) {
             const int rx = rx0 + q;
             if (rx >= n_r) break;
-            double nr, ni;
+            double nr[2], ni[2];
             if (fp.noise_in) {
-                nr = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rx];
-                ni = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rx + 1];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int rxd = rx + d < n_r ? rx + d : rx;
+                    nr[d] = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rxd];
+                    ni[d] = fp.noise_in[((size_t)frame * T + t) * n_r * 2 + 2 * rxd + 1];
+                }
             } else {
                 uint32_t w[4];
-                ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_NOISE, (uint32_t)(t * n_r + rx), w);
-                box_muller(w[0], w[1], nr, ni);
+                ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_NOISE, (uint32_t)(t * ((n_r + 1) >> 1) + (rx >> 1)), w);
+                box_muller_fast(w[0], w[1], nr[0], ni[0]);
+                box_muller_fast(w[2], w[3], nr[1], ni[1]);
             }
-            reinterpret_cast<double2*>(fp.y_cp)[((size_t)frame * T + t) * n_r + rx] =
-                make_double2(yr[q] + sig * nr, yi[q] + sig * ni);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                if (rx + d < n_r)
+                    reinterpret_cast<double2*>(fp.y_cp)[((size_t)frame * T + t) * n_r + rx + d] =
+                        make_double2(yr[q + d] + sig * nr[d], yi[q + d] + sig * ni[d]);
         }
     }
 }
