@@ -31,6 +31,7 @@ struct ClusterGeom {
 };
 
 constexpr int CL_NT = 256;
+constexpr int CL_NG = 12;                         // doubles a thread may own in a gather: C * per <= CL_NG * CL_NT
 constexpr uint32_t CL_SPIN_LIMIT = 1u << 22;     // polls per wait before giving up (each poll >= ~0.5 us)
 
 static bool cluster_geometry(int n_res, int n_in, int n_out, bool harvest, ClusterGeom* cg) {
@@ -42,6 +43,7 @@ static bool cluster_geometry(int n_res, int n_in, int n_out, bool harvest, Clust
     const int C = (n_res + R - 1) / R;
     if (C > 64 || n_out > 16 || n_in > 64) return false;
     cg->R = R; cg->C = C; cg->K = K; cg->per = R + (harvest ? 0 : n_out);
+    if (C * cg->per > CL_NG * CL_NT) return false;
     // LDS: matrix + operand vector + gathered partials + small tables; checked by the launcher
     return true;
 }
@@ -122,29 +124,45 @@ __global__ __launch_bounds__(CL_NT) void recur_cluster_kernel(RecurParams p, Clu
         __hip_atomic_store(dst, tag | (bits & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    // gather every workgroup's slice of step `step_tag` into v[0:n_res] and pbuf; false on time-out
+    // gather every workgroup's slice of step `step_tag` into v[0:n_res] and pbuf; false on time-out.  A thread owns up
+    // to CL_NG doubles (two granules each): it issues ALL its loads, then checks the tags, and re-polls only what has
+    // not arrived -- one L2 round trip per step when the producers are on time, not one per granule.
     auto gather = [&](int step_tag) -> bool {
         const int total = C * per;
+        unsigned pending = 0;
+#pragma unroll
+        for (int j = 0; j < CL_NG; ++j)
+            if (tid + j * CL_NT < total) pending |= 1u << j;
+        uint32_t spins = 0;
         bool ok = true;
-        for (int i = tid; i < total; i += CL_NT) {
-            const unsigned long long* src = xch + ((size_t)(step_tag & 1) * C * per + i) * 2;
-            unsigned long long lo = 0, hi = 0;
-            uint32_t spins = 0;
-            while (true) {
-                lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(lo >> 32) == (unsigned)step_tag && (unsigned)(hi >> 32) == (unsigned)step_tag) break;
+        while (pending) {
+            unsigned long long lo[CL_NG], hi[CL_NG];
+#pragma unroll
+            for (int j = 0; j < CL_NG; ++j)
+                if (pending & (1u << j)) {
+                    const unsigned long long* src = xch + ((size_t)(step_tag & 1) * total + tid + j * CL_NT) * 2;
+                    lo[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[j] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+            for (int j = 0; j < CL_NG; ++j)
+                if ((pending & (1u << j)) && (unsigned)(lo[j] >> 32) == (unsigned)step_tag &&
+                    (unsigned)(hi[j] >> 32) == (unsigned)step_tag) {
+                    const double val = __builtin_bit_cast(double, (hi[j] << 32) | (lo[j] & 0xffffffffULL));
+                    const int i = tid + j * CL_NT;
+                    const int cc = i / per, jj = i - cc * per;
+                    if (jj < R) { if (cc * R + jj < n_res) v[cc * R + jj] = val; }
+                    else pbuf[cc * 16 + (jj - R)] = val;
+                    pending &= ~(1u << j);
+                }
+            if (pending) {
                 if (++spins > CL_SPIN_LIMIT ||
                     ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     ok = false;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
-            const double val = __builtin_bit_cast(double, (hi << 32) | (lo & 0xffffffffULL));
-            const int cc = i / per, j = i - cc * per;
-            if (j < R) { if (cc * R + j < n_res) v[cc * R + j] = val; }
-            else pbuf[cc * 16 + (j - R)] = val;
         }
         if (!ok) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
