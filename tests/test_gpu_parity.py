@@ -503,7 +503,11 @@ def test_odd_shapes_and_flags(amd, precision, n_in, n_out, tf):
             want = o.predict(u[b], tr, continuation=False)
             assert rel_err(got[b], want) < tol, (precision, n_in, n_out, tr, b, rel_err(got[b], want))
     one = bank.predict(u[:1], F, transient=0, precision=precision).cpu().numpy()     # a single frame
-    np.testing.assert_array_equal(one[0], bank.predict(u, F, transient=0, precision=precision).cpu().numpy()[0])
+    full0 = bank.predict(u, F, transient=0, precision=precision).cpu().numpy()[0]
+    if precision == "f64":      # ONE float64 sequence runs on the LDS-resident cluster kernel: other summation order
+        assert rel_err(one[0], full0) < 1e-12
+    else:
+        np.testing.assert_array_equal(one[0], full0)
 
 
 def test_argument_validation_on_device(amd):
