@@ -100,6 +100,9 @@ Knobs& knobs() {
         x.big_gemm = (v && v[0] == '0') ? 0 : 1;
         v = getenv("ESN_CLUSTER");
         x.cluster = (v && v[0] == '0') ? 0 : 1;
+        x.gen_ko = 0;
+        v = getenv("ESN_BIG_NT");
+        x.big_nt = (v && v[0] == '2') ? 2 : 4;
         return x;
     }();
     return k;
@@ -176,6 +179,8 @@ int esn_debug_set(const char* key, const char* value) {
     }
     if (!strcmp(key, "big_gemm")) { k.big_gemm = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "cluster")) { k.cluster = (value && value[0] == '0') ? 0 : 1; return 0; }
+    if (!strcmp(key, "gen_ko")) { k.gen_ko = value ? atoi(value) : 0; return 0; }
+    if (!strcmp(key, "big_nt")) { k.big_nt = (value && value[0] == '2') ? 2 : 4; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }
 
@@ -577,6 +582,7 @@ int esn_gen_frames(int n_frames, int frames_per_block, int n_sub, int cp, int n_
     fp.p_i = p_i; fp.a_clip = a_clip; fp.no = no; fp.taps = taps; fp.bits_in = bits_in; fp.noise_in = noise_in;
     fp.seed = seed; fp.frame_offset = frame_offset; fp.bits = bits; fp.x_cp = x_cp; fp.y_cp = y_cp;
     fp.ls_pattern = ls_pattern ? 1 : 0;
+    fp.ko = knobs().gen_ko;
     int e = launch_gen_frames(fp, (hipStream_t)stream);
     if (e == -1) return fail(-2, "esn_gen_frames: frame does not fit LDS");
     return hip_fail(e, "esn_gen_frames");

@@ -102,6 +102,7 @@ struct FrameGenParams {
     double* x_cp;             // optional complex [B][T][n_t] (pre-PA: the ESN teacher)
     double* y_cp;             // complex [B][T][n_r]
     int ls_pattern;           // 1: sparse LS pilot, subcarrier sc carries only tx = sc % n_t (driver:330-333)
+    int ko;                   // diagnostic (esn_debug_set "gen_ko"): bit0 no AWGN draw, bit1 no channel MACs, bit2 no IFFT, bit3 no PA
 };
 
 // baseline equaliser (esn_baseline.hip)
@@ -198,6 +199,8 @@ struct Knobs {
                            // correct but 17 % slower than the skewed LDS-state kernel on MI355X)
     int big_gemm;          // 1 (default): N_res > 1024 predict runs as one GEMM launch per step when a workspace is given
     int cluster;           // 1 (default): ONE float64 sequence runs on the LDS-resident cluster kernel when a workspace is given
+    int big_nt;            // N_res > 1024 predict: column tiles per wave of big_step_kernel, 4 (default: 4 waves of 128 x 128) or 2
+    int gen_ko;            // frame generator knock-out mask for tools/time_gen.py (timing only, wrong frames)
 };
 Knobs& knobs();
 

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
     }
     __syncthreads();
     // ---- x = N * ifft(X): un-normalised inverse DFT, radix-2 DIT on bit-reversed input, per tx
-    for (int s = 1; s <= fp.log2n; ++s) {
+    for (int s = 1; s <= ((fp.ko & 4) ? 0 : fp.log2n); ++s) {
         const int hm = 1 << (s - 1), tstep = N >> s;
         for (int e = tid; e < n_t * half; e += nth) {
             const int tx = e / half, b = e % half;
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
             fp.x_cp[((size_t)frame * T + t) * n_t * 2 + 2 * tx] = xr;
             fp.x_cp[((size_t)frame * T + t) * n_t * 2 + 2 * tx + 1] = xi;
         }
-        const double mag = sqrt(xr * xr + xi * xi) / aclip;
-        const double gpa = 1.0 / sqrt(1.0 + mag * mag);
+        const double mag = (fp.ko & 8) ? 0.0 : sqrt(xr * xr + xi * xi) / aclip;
+        const double gpa = (fp.ko & 8) ? 1.0 : 1.0 / sqrt(1.0 + mag * mag);
         xpa[(size_t)tx * T + t] = make_double2(xr * gpa, xi * gpa);
     }
     __syncthreads();
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
                 }
             }
         };
-        if (isi == 8) channel(std::integral_constant<int, 8>{}); else channel(std::integral_constant<int, 0>{});
+        if (!(fp.ko & 2)) { if (isi == 8) channel(std::integral_constant<int, 8>{}); else channel(std::integral_constant<int, 0>{}); }
         if (!live) continue;
         // AWGN: one Philox call per PAIR of receive antennas (4 words = two complex samples), counter (t, rx / 2)
 #pragma unroll
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
             const int rx = rx0 + q;
             if (rx >= n_r) break;
             double nr[2], ni[2];
-            if (fp.noise_in) {
+            if (fp.ko & 1) { nr[0] = nr[1] = ni[0] = ni[1] = 0.0; }
+            else if (fp.noise_in) {
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     const int rxd = rx + d < n_r ? rx + d : rx;

@@ -195,13 +195,21 @@ __global__ __launch_bounds__(256) void big_prep_kernel(BigParams bp) {
     }
 }
 
-template <typename TR, int NOISE>
-__global__ __launch_bounds__(512) void big_step_kernel(BigParams bp) {
+// NT = column tiles (of 32 frames) per wave: 2 -> 8 waves of 128 x 64 (two per SIMD, 128 accumulator registers), the round-2
+// shape; 4 -> 4 waves of 128 x 128 (ONE per SIMD, 256 accumulator registers of its 512).  At NT = 2 a k-group costs a wave 6
+// fragment reads for 8 MFMAs: 8 waves x 24 KB per 64-deep chunk + the 64 KB the LDS-DMA writes = 256 KB per 1024 MFMA cycles,
+// i.e. the whole LDS bandwidth (256 B/clk) at full matrix rate -- the matrix pipe sat at 53 %.  At NT = 4 it is 8 reads for
+// 16 MFMAs: 192 KB per 2048 cycles = 94 B/clk.
+template <typename TR, int NOISE, int NT>
+__global__ __launch_bounds__(1024 / NT) void big_step_kernel(BigParams bp) {
+    constexpr int NW = 16 / NT;                          // waves: 2 (rows) x NW/2 (frames)
+    constexpr int WNC = NW / 2;                          // wave columns
+    constexpr int DT = 8 / WNC;                          // 32-row / 32-frame operand tiles a wave fetches per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RecurParams& p = bp.r;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;             // 2 x 4 waves: rows 128 wm.., frames 64 wn..
+    const int wm = wave / WNC, wn = wave % WNC;          // 2 x WNC waves: rows 128 wm.., frames 32 NT wn..
     const int r = lane & 31, h = lane >> 5;
     const int n_res = p.n_res;
     const int nkg = bp.nkg;
@@ -219,9 +227,9 @@ __global__ __launch_bounds__(512) void big_step_kernel(BigParams bp) {
     // ---- main loop: Kp/64 chunks of four k-groups, LDS-DMA double-buffered ---------------------------
     const int lane16 = lane * 16;
     const size_t x_bytes = (size_t)bp.n_slots * p.g.Kp * 2;
-    // wave w < 4 fetches row tiles 2w, 2w+1 of A; wave w >= 4 column tiles 2(w-4), 2(w-4)+1 of B: 8 pieces each
-    const bool is_a = wave < 4;
-    const int pair = (wave & 3) * 2;
+    // the first half of the waves fetches DT row tiles of A each, the second half DT column tiles of B: 4 DT pieces each
+    const bool is_a = wave < WNC;
+    const int pair = (wave % WNC) * DT;
     const int src_t0 = (is_a ? (m * 8 + pair) : ((slot0 >> 5) + pair)) * nkg;
     const int dst_off = (is_a ? 0 : 32768) + pair * 4096;
     // one descriptor per wave, built from values the compiler can PROVE wave-uniform (readfirstlane of the
@@ -235,31 +243,31 @@ __global__ __launch_bounds__(512) void big_step_kernel(BigParams bp) {
     auto issue = [&](int c, int buf) {
         char* dst = stage + (size_t)buf * BIG_STAGE + dst_off;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < DT; ++t)
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rsrc, (__attribute__((address_space(3))) void*)(dst + (t * 4 + kg) * 1024),
                                                          16, lane16, (src_t0 + t * nkg + 4 * c + kg) * 1024, 0, 0);
     };
-    f32x16 acc[4][2];
+    f32x16 acc[4][NT];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
     auto compute = [&](int buf) {
         const char* ab = stage + (size_t)buf * BIG_STAGE + (size_t)(wm * 4) * 4096 + lane16;
-        const char* bb = stage + (size_t)buf * BIG_STAGE + 32768 + (size_t)(wn * 2) * 4096 + lane16;
+        const char* bb = stage + (size_t)buf * BIG_STAGE + 32768 + (size_t)(wn * NT) * 4096 + lane16;
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
-            u32x4 a[4], b[2];
+            u32x4 a[4], b[NT];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const u32x4*>(ab + mt * 4096 + kg * 1024);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const u32x4*>(bb + nt * 4096 + kg * 1024);
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const u32x4*>(bb + nt * 4096 + kg * 1024);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) TR::mma32(acc[mt][nt], a[mt], b[nt]);
         }
@@ -268,7 +276,8 @@ __global__ __launch_bounds__(512) void big_step_kernel(BigParams bp) {
     issue(0, 0);
     for (int c = 0; c + 1 < nch; ++c) {
         issue(c + 1, (c + 1) & 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's pieces of chunk c have landed
+        if constexpr (DT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's pieces of chunk c have landed
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // ... and everybody else's
         compute(c & 1);
         __builtin_amdgcn_s_barrier();                          // chunk c read: its buffer may be refilled
@@ -284,11 +293,11 @@ __global__ __launch_bounds__(512) void big_step_kernel(BigParams bp) {
     const char* wo_base = reinterpret_cast<const char*>(p.packed_wout) + bp.wo_big_off;
     const __amdgpu_buffer_rsrc_t xo_rsrc = __builtin_amdgcn_make_buffer_rsrc(bp.x_out, 0, (int)x_bytes, 0x00020000);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int fcol = wn * 64 + nt * 32 + r;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int fcol = wn * 32 * NT + nt * 32 + r;
         int fgrp;
         const int fr = slot_frame(p, slot0 + fcol, fgrp);
-        const int ct_g = (slot0 >> 5) + wn * 2 + nt;
+        const int ct_g = (slot0 >> 5) + wn * NT + nt;
         // the column tile's two 16-frame halves may belong to different groups (different W_out)
         const int g_lo = (ct_g * 32) / p.Fpad, g_hi = (ct_g * 32 + 16) / p.Fpad;       // wave-uniform
         uint32_t key = 0;
@@ -378,11 +387,16 @@ static int launch_big_t(const RecurParams& rp, size_t wo_big_off, void* workspac
     if (e != hipSuccess) return (int)e;
     const int n_nt8 = (bp.n_slots / 256 + 7) / 8;
     const dim3 grid(8 * n_nt8 * bp.n_mt);
-    const void* k_none = reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_NONE>);
-    const void* k_tens = reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_TENSOR>);
-    const void* k_cnt = reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_COUNTER>);
-    e = hipFuncSetAttribute(rp.noise_mode == ESN_NOISE_NONE ? k_none : rp.noise_mode == ESN_NOISE_TENSOR ? k_tens : k_cnt,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+    const bool wide = knobs().big_nt != 2;               // 4 waves of 128 x 128 (default) or the round-2 8 waves of 128 x 64
+    const void* kern[2][3] = {
+        {reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_NONE, 2>),
+         reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_TENSOR, 2>),
+         reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_COUNTER, 2>)},
+        {reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_NONE, 4>),
+         reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_TENSOR, 4>),
+         reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_COUNTER, 4>)}};
+    const int ni = rp.noise_mode == ESN_NOISE_NONE ? 0 : rp.noise_mode == ESN_NOISE_TENSOR ? 1 : 2;
+    e = hipFuncSetAttribute(kern[wide ? 1 : 0][ni], hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
     if (e != hipSuccess) return (int)e;
     for (int s = 0; s <= rp.S; ++s) {
         // prep(s): partials of X_s (from GEMM s-1, in YP[s & 1]) -> Y row s-1; [U_s ; F_s] -> image X[s & 1]
@@ -394,13 +408,24 @@ static int launch_big_t(const RecurParams& rp, size_t wo_big_off, void* workspac
         if (s == rp.S) break;
         bp.x_in = X[s & 1]; bp.x_out = X[(s + 1) & 1];
         bp.yp_out = YP[(s + 1) & 1];
-        switch (rp.noise_mode) {
-            case ESN_NOISE_NONE:
-                hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_NONE>), grid, dim3(512), BIG_LDS, stream, bp); break;
-            case ESN_NOISE_TENSOR:
-                hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_TENSOR>), grid, dim3(512), BIG_LDS, stream, bp); break;
-            default:
-                hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_COUNTER>), grid, dim3(512), BIG_LDS, stream, bp); break;
+        if (wide) {
+            switch (rp.noise_mode) {
+                case ESN_NOISE_NONE:
+                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_NONE, 4>), grid, dim3(256), BIG_LDS, stream, bp); break;
+                case ESN_NOISE_TENSOR:
+                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_TENSOR, 4>), grid, dim3(256), BIG_LDS, stream, bp); break;
+                default:
+                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_COUNTER, 4>), grid, dim3(256), BIG_LDS, stream, bp); break;
+            }
+        } else {
+            switch (rp.noise_mode) {
+                case ESN_NOISE_NONE:
+                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_NONE, 2>), grid, dim3(512), BIG_LDS, stream, bp); break;
+                case ESN_NOISE_TENSOR:
+                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_TENSOR, 2>), grid, dim3(512), BIG_LDS, stream, bp); break;
+                default:
+                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_COUNTER, 2>), grid, dim3(512), BIG_LDS, stream, bp); break;
+            }
         }
     }
     return (int)hipGetLastError();

@@ -35,7 +35,13 @@ def test_bench_line_small_run():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
     assert set(c["legs"]) == {"single_thread", "default_blas_threads", "process_per_core"}
-    assert c["legs"]["single_thread"]["cores"] == 1 and c["host_cpu"] and c["host_cores_visible"] >= c["cores"]
+    assert c["legs"]["single_thread"]["cores"] == 1 and c["host_cpu"] and c["host_physical_cores"] >= 1
+    assert c["cores"] <= c["host_logical_cpus"] and (c["host_cpu_quota"] is None or c["cores"] <= c["host_cpu_quota"] + 0.5)
+    # what a user of DetectorSweep.run gets (generation + train + predict + detect + host syncs)
+    sw = d["sweep"]
+    assert sw["unit"] == d["unit"] and sw["frames"] >= 1e6 and len(sw["ber"]) == len(sw["ebno_db"]) >= 3
+    assert abs(sw["value"] - sw["frames"] / sw["wall_s"]) < 1e-6 * sw["value"] and sw["fits_repaired"] == 0
+    assert all(a > b for a, b in zip(sw["ber"], sw["ber"][1:]))                      # falling with Eb/No
     # reference-precision and reference-faithful sub-records ride in the same line (N=1)
     for prec, peak in (("f32", 157.3), ("f64", 78.6)):
         p_ = d["precisions"][prec]

@@ -1,5 +1,5 @@
-"""world_size-2 gloo test of the multi-GPU path's host logic: blocks dealt
-round-robin, per-block random streams independent of rank, ONE all_reduce(SUM) of int64
+"""world_size-2 gloo test of the multi-GPU path's host logic: contiguous block
+ranges per rank, per-block random streams independent of rank, ONE all_reduce(SUM) of int64
 counters -> summed error counts bit-identical to the single-process result.  The per-block
 detector here is the CPU oracle on a tiny configuration (the GPU kernels are covered by the
 -m gpu tests); what is under test is the partition + reduction the product uses."""
