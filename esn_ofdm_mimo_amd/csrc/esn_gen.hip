@@ -111,6 +111,7 @@ __global__ void gen_taps_kernel(TapParams tp) {
 // scalar loads straight from the tap array (round 2 kept them in LDS and read them with an 8-way bank
 // conflict per MAC: 75 % of the LDS cycles were conflicts, 6.2 ms per 153 600 frames).
 constexpr int GEN_RXG = 4;      // receive antennas per wave task
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
     double2* X = reinterpret_cast<double2*>(gsm);            // [n_t][N]   freq -> time (in place)
     double2* xpa = X + (size_t)n_t * N;                       // [n_t][T]   post-PA time signal
     double2* tw = xpa + (size_t)n_t * T;                      // [N/2]      exp(+2 pi i k / N)
+    double2* ctap = tw + (N >> 1);                            // [n_r][n_t][isi] this block's taps
     const int tid = threadIdx.x, nth = blockDim.x;
     const int frame = blockIdx.x;
     const int blk = frame / fp.frames_per_block;
@@ -132,6 +134,8 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
         sincospi(2.0 * (double)k / (double)N, &sn, &cs);
         tw[k] = make_double2(cs, sn);
     }
+    for (int i = tid; i < n_r * n_t * isi; i += nth)
+        ctap[i] = reinterpret_cast<const double2*>(fp.taps)[(size_t)blk * n_r * n_t * isi + i];
     // ---- bits -> constellation point (index = sum_b bit_b 2^b = i*side + j; Re = pam[i], Im = pam[j])
     // random payload: ONE Philox call per 128 bits = 4 (32 / m) symbols (v_mul_hi_u32 is a quarter-rate instruction:
     // a call per symbol was 512 calls per frame for 2 048 bits); thread t owns call t
@@ -153,6 +157,35 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
             for (int b = 0; b < m; ++b)
                 idx |= (uint32_t)(fp.bits_in[((size_t)frame * N * m + (size_t)sc * m + b) * n_t + tx] & 1) << b;
             place(e, idx);
+        }
+    } else if (m == 4 && n_t == 4) {
+        // headline shape: a call's 32 symbols are 8 whole subcarriers; a subcarrier's 16 bit-bytes (bit b of tx at
+        // b n_t + tx) leave as ONE 16-byte store instead of 16 byte stores (2 048 byte stores per frame were half of
+        // the kernel's floor)
+        for (int call = tid; call * 32 < N * 4; call += nth) {
+            uint32_t w[4];
+            ph((uint32_t)gf, (uint32_t)(gf >> 32), PURPOSE_BITS, (uint32_t)call, w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int sc = call * 8 + q * 2 + h2;
+                    const uint32_t four = (w[q] >> (16 * h2)) & 0xffffu;          // the subcarrier's four 4-bit symbols
+                    u32x4v ob;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)                                   // word b: bit b of tx 0..3, one byte each
+                        ob[b] = ((four >> b) & 1u) | (((four >> (4 + b)) & 1u) << 8) | (((four >> (8 + b)) & 1u) << 16) |
+                                (((four >> (12 + b)) & 1u) << 24);
+                    *reinterpret_cast<u32x4v*>(fp.bits + ((size_t)frame * N + sc) * 16) = ob;
+                    const int rv = (int)(__brev((unsigned)sc) >> (32 - fp.log2n));
+#pragma unroll
+                    for (int tx = 0; tx < 4; ++tx) {
+                        const uint32_t idx = (four >> (4 * tx)) & 15u;
+                        const bool on = !fp.ls_pattern || ((sc & 3) == tx);
+                        X[(size_t)tx * N + rv] = on ? make_double2((2.0 * (int)(idx >> 2) - 3.0) / norm, (2.0 * (int)(idx & 3) - 3.0) / norm)
+                                                    : make_double2(0.0, 0.0);
+                    }
+                }
         }
     } else {
         for (int call = tid; call * spc < N * n_t; call += nth) {
@@ -203,7 +236,6 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
     const double sig = sqrt((double)T * fp.no * 0.5);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6;
     const int t_chunks = (T + 63) >> 6, rx_groups = (n_r + GEN_RXG - 1) / GEN_RXG;
-    const double* taps_blk = fp.taps + (size_t)blk * n_r * n_t * isi * 2;
     for (int task = wave; task < t_chunks * rx_groups; task += nwaves) {
         const int rx0 = __builtin_amdgcn_readfirstlane((task / t_chunks) * GEN_RXG);
         const int t = (task % t_chunks) * 64 + lane;
@@ -211,15 +243,9 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
         double yr[GEN_RXG], yi[GEN_RXG];
 #pragma unroll
         for (int q = 0; q < GEN_RXG; ++q) { yr[q] = 0.0; yi[q] = 0.0; }
-        // taps: wave-uniform addresses read through the constant address space, i.e. s_load into SGPRs (the tap
-        // array was written by an earlier launch, so the scalar cache is coherent with it)
-        typedef const __attribute__((address_space(4))) double* cptr_t;
-        auto uniform_ptr = [](const double* q) -> cptr_t {           // both halves through readfirstlane: provably SGPRs
-            const uint64_t a = (uint64_t)q;
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
-            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-            return (cptr_t)(((uint64_t)hi << 32) | lo);
-        };
+        // taps: every lane of the wave reads the SAME LDS address (a broadcast: one LDS pass per lane group, no bank
+        // conflict -- round 2 read them per (rx, tx, k) with rx varying across lanes: 8-way conflicts).  (Scalar loads
+        // through the constant address space were tried first: correct, 16 dependent s_load round trips per task.)
         auto channel = [&](auto isi_tag) {
             constexpr int ISI = decltype(isi_tag)::value;            // 0 = run-time tap count
             const int ntap = ISI ? ISI : isi;
@@ -233,12 +259,12 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
 #pragma unroll
                     for (int q = 0; q < GEN_RXG; ++q) {
                         const int rx = rx0 + q < n_r ? rx0 + q : n_r - 1;     // (uniform; clamped, result unused)
-                        cptr_t c = uniform_ptr(taps_blk + ((size_t)rx * n_t + tx) * ISI * 2);
+                        const double2* c = ctap + ((size_t)rx * n_t + tx) * ISI;
 #pragma unroll
                         for (int k = 0; k < ISI; ++k) {
-                            const double cr = c[2 * k], ci = c[2 * k + 1];
-                            yr[q] += cr * xv[k].x - ci * xv[k].y;
-                            yi[q] += cr * xv[k].y + ci * xv[k].x;
+                            const double2 cv = c[k];
+                            yr[q] += cv.x * xv[k].x - cv.y * xv[k].y;
+                            yi[q] += cv.x * xv[k].y + cv.y * xv[k].x;
                         }
                     }
                 } else {
@@ -247,10 +273,9 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
 #pragma unroll
                         for (int q = 0; q < GEN_RXG; ++q) {
                             const int rx = rx0 + q < n_r ? rx0 + q : n_r - 1;
-                            cptr_t c = uniform_ptr(taps_blk + (((size_t)rx * n_t + tx) * isi + k) * 2);
-                            const double cr = c[0], ci = c[1];
-                            yr[q] += cr * xv.x - ci * xv.y;
-                            yi[q] += cr * xv.y + ci * xv.x;
+                            const double2 cv = ctap[((size_t)rx * n_t + tx) * isi + k];
+                            yr[q] += cv.x * xv.x - cv.y * xv.y;
+                            yi[q] += cv.x * xv.y + cv.y * xv.x;
                         }
                     }
                 }
@@ -295,7 +320,8 @@ int launch_gen_taps(const TapParams& tp, hipStream_t stream) {
 
 int launch_gen_frames(const FrameGenParams& fp, hipStream_t stream) {
     const int T = fp.n_sub + fp.cp;
-    const size_t lds = sizeof(double2) * ((size_t)fp.n_t * fp.n_sub + (size_t)fp.n_t * T + fp.n_sub / 2);
+    const size_t lds = sizeof(double2) * ((size_t)fp.n_t * fp.n_sub + (size_t)fp.n_t * T + fp.n_sub / 2 +
+                                          (size_t)fp.n_r * fp.n_t * fp.isi);
     if (lds > 150 * 1024) return -1;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gen_frames_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -259,17 +259,44 @@ __global__ __launch_bounds__(1024 / NT) void big_step_kernel(BigParams bp) {
     auto compute = [&](int buf) {
         const char* ab = stage + (size_t)buf * BIG_STAGE + (size_t)(wm * 4) * 4096 + lane16;
         const char* bb = stage + (size_t)buf * BIG_STAGE + 32768 + (size_t)(wn * NT) * 4096 + lane16;
+        if constexpr (NT == 4) {
+            // one wave per SIMD: nobody else covers an LDS latency, so the fragments of k-group kg+1 are requested
+            // BEFORE the 16 MFMAs of k-group kg (two register sets); left to itself the compiler reads one B fragment
+            // at a time and waits for it in front of every four MFMAs
+            u32x4 a[2][4], b[2][NT];
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            u32x4 a[4], b[NT];
+            for (int mt = 0; mt < 4; ++mt) a[0][mt] = *reinterpret_cast<const u32x4*>(ab + mt * 4096);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const u32x4*>(ab + mt * 4096 + kg * 1024);
+            for (int nt = 0; nt < NT; ++nt) b[0][nt] = *reinterpret_cast<const u32x4*>(bb + nt * 4096);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const u32x4*>(bb + nt * 4096 + kg * 1024);
+            for (int kg = 0; kg < 4; ++kg) {
+                const int cur = kg & 1, nxt = cur ^ 1;
+                if (kg + 1 < 4) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                    for (int mt = 0; mt < 4; ++mt) a[nxt][mt] = *reinterpret_cast<const u32x4*>(ab + mt * 4096 + (kg + 1) * 1024);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) TR::mma32(acc[mt][nt], a[mt], b[nt]);
+                    for (int nt = 0; nt < NT; ++nt) b[nxt][nt] = *reinterpret_cast<const u32x4*>(bb + nt * 4096 + (kg + 1) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) TR::mma32(acc[mt][nt], a[cur][mt], b[cur][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                u32x4 a[4], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const u32x4*>(ab + mt * 4096 + kg * 1024);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const u32x4*>(bb + nt * 4096 + kg * 1024);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) TR::mma32(acc[mt][nt], a[mt], b[nt]);
+            }
         }
     };
     const int nch = nkg / 4;
