@@ -102,7 +102,9 @@ Knobs& knobs() {
         x.cluster = (v && v[0] == '0') ? 0 : 1;
         x.gen_ko = 0;
         v = getenv("ESN_BIG_NT");
-        x.big_nt = (v && v[0] == '2') ? 2 : 4;
+        x.big_nt = (v && v[0] == '4') ? 4 : 2;
+        v = getenv("ESN_BIG_PIPE");
+        x.big_pipe = (v && v[0] == '0') ? 0 : 1;
         return x;
     }();
     return k;
@@ -180,7 +182,8 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "big_gemm")) { k.big_gemm = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "cluster")) { k.cluster = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "gen_ko")) { k.gen_ko = value ? atoi(value) : 0; return 0; }
-    if (!strcmp(key, "big_nt")) { k.big_nt = (value && value[0] == '2') ? 2 : 4; return 0; }
+    if (!strcmp(key, "big_nt")) { k.big_nt = (value && value[0] == '4') ? 4 : 2; return 0; }
+    if (!strcmp(key, "big_pipe")) { k.big_pipe = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }
 

@@ -199,7 +199,8 @@ struct Knobs {
                            // correct but 17 % slower than the skewed LDS-state kernel on MI355X)
     int big_gemm;          // 1 (default): N_res > 1024 predict runs as one GEMM launch per step when a workspace is given
     int cluster;           // 1 (default): ONE float64 sequence runs on the LDS-resident cluster kernel when a workspace is given
-    int big_nt;            // N_res > 1024 predict: column tiles per wave of big_step_kernel, 4 (default: 4 waves of 128 x 128) or 2
+    int big_nt;            // N_res > 1024 predict: 4 = the 4-wave 128 x 128 variant of big_step_kernel (slower: A/B only); default 2
+    int big_pipe;          // 1 (default): big_step_kernel's four-stage pipelined main loop; 0: the round-2 loop (A/B runs)
     int gen_ko;            // frame generator knock-out mask for tools/time_gen.py (timing only, wrong frames)
 };
 Knobs& knobs();

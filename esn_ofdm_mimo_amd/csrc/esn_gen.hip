@@ -263,8 +263,10 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
 #pragma unroll
                         for (int k = 0; k < ISI; ++k) {
                             const double2 cv = c[k];
-                            yr[q] += cv.x * xv[k].x - cv.y * xv[k].y;
-                            yi[q] += cv.x * xv[k].y + cv.y * xv[k].x;
+                            // (explicit FMAs: -ffp-contract=off would make a complex MAC 4 mul + 4 add; the float64 FMA rate
+                            //  bounds this loop)
+                            yr[q] = fma(-cv.y, xv[k].y, fma(cv.x, xv[k].x, yr[q]));
+                            yi[q] = fma(cv.y, xv[k].x, fma(cv.x, xv[k].y, yi[q]));
                         }
                     }
                 } else {
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(256) void gen_frames_kernel(FrameGenParams fp) {
                         for (int q = 0; q < GEN_RXG; ++q) {
                             const int rx = rx0 + q < n_r ? rx0 + q : n_r - 1;
                             const double2 cv = ctap[((size_t)rx * n_t + tx) * isi + k];
-                            yr[q] += cv.x * xv.x - cv.y * xv.y;
-                            yi[q] += cv.x * xv.y + cv.y * xv.x;
+                            yr[q] = fma(-cv.y, xv.y, fma(cv.x, xv.x, yr[q]));
+                            yi[q] = fma(cv.y, xv.x, fma(cv.x, xv.y, yi[q]));
                         }
                     }
                 }

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void big_prep_kernel(BigParams bp) {
 // fragment reads for 8 MFMAs: 8 waves x 24 KB per 64-deep chunk + the 64 KB the LDS-DMA writes = 256 KB per 1024 MFMA cycles,
 // i.e. the whole LDS bandwidth (256 B/clk) at full matrix rate -- the matrix pipe sat at 53 %.  At NT = 4 it is 8 reads for
 // 16 MFMAs: 192 KB per 2048 cycles = 94 B/clk.
-template <typename TR, int NOISE, int NT>
+template <typename TR, int NOISE, int NT, bool PIPE>
 __global__ __launch_bounds__(1024 / NT) void big_step_kernel(BigParams bp) {
     constexpr int NW = 16 / NT;                          // waves: 2 (rows) x NW/2 (frames)
     constexpr int WNC = NW / 2;                          // wave columns
@@ -299,6 +299,57 @@ __global__ __launch_bounds__(1024 / NT) void big_step_kernel(BigParams bp) {
             }
         }
     };
+    if constexpr (PIPE) {
+        // Round-3 main loop (NT = 2).  The round-2 loop below puts every wave's eight DMA launches of chunk c+1 in
+        // front of the wait and the barrier of chunk c: all eight waves launch (8 x ~100 cycles each: the guide's
+        // LDS-DMA issue price inside a busy phase), THEN all eight compute (1024 MFMA cycles per wave) -- the matrix
+        // pipe idles through every launch burst (53 % busy).  Here a stage is 32 deep (32 KB), FOUR stages are in
+        // flight, a stage's four launches per wave are spread between the MFMAs of the stage being multiplied (the
+        // pipe keeps running while the wave issues them), a stage has a whole stage time to land before it is waited
+        // for, and there is ONE barrier per stage: a buffer is refilled three stages after it was read, behind the
+        // barrier every wave passes after reading it.
+        static_assert(NT == 2, "pipelined main loop: 8 waves of 128 x 64");
+        constexpr int STG = 32768;
+        const int half_off = is_a ? 0 : 16384;
+        auto issue_piece = [&](int st, int j) {               // j < 4: operand tile pair + (j >> 1), k-group 2 st + (j & 1)
+            char* dst = stage + (size_t)(st & 3) * STG + half_off + (pair + (j >> 1)) * 2048 + (j & 1) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rsrc, (__attribute__((address_space(3))) void*)dst, 16, lane16,
+                                                     (src_t0 + (j >> 1) * nkg + 2 * st + (j & 1)) * 1024, 0, 0);
+        };
+        const int nst = nkg / 2;
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+            if (st < nst) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) issue_piece(st, j);
+            }
+        for (int st = 0; st < nst; ++st) {
+            if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // this wave's pieces of stage st have landed
+            else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // ... everybody's; and stage st-1 has been read by all
+            const bool more = st + 3 < nst;
+            const char* ab = stage + (size_t)(st & 3) * STG + (size_t)(wm * 4) * 2048 + lane16;
+            const char* bb = stage + (size_t)(st & 3) * STG + 16384 + (size_t)(wn * 2) * 2048 + lane16;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                u32x4 a[4], b[2];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const u32x4*>(ab + mt * 2048 + kg * 1024);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const u32x4*>(bb + nt * 2048 + kg * 1024);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        TR::mma32(acc[mt][nt], a[mt], b[nt]);
+                        if (mt == 1 && more) issue_piece(st + 3, kg * 2 + nt);      // in the issue shadow of the MFMAs
+                    }
+                }
+            }
+        }
+        __syncthreads();                                           // stage buffers free (the epilogue's scratch aliases them)
+    } else {
     const int nch = nkg / 4;
     issue(0, 0);
     for (int c = 0; c + 1 < nch; ++c) {
@@ -313,6 +364,7 @@ __global__ __launch_bounds__(1024 / NT) void big_step_kernel(BigParams bp) {
     __builtin_amdgcn_s_barrier();
     compute((nch - 1) & 1);
     __syncthreads();                                           // stage buffers free (the epilogue's scratch aliases them)
+    }
 
     // ---- epilogue: activation + noise -> next state image; read-out partial ---------------------------
     const float noise = (float)p.noise;
@@ -414,17 +466,18 @@ static int launch_big_t(const RecurParams& rp, size_t wo_big_off, void* workspac
     if (e != hipSuccess) return (int)e;
     const int n_nt8 = (bp.n_slots / 256 + 7) / 8;
     const dim3 grid(8 * n_nt8 * bp.n_mt);
-    const bool wide = knobs().big_nt != 2;               // 4 waves of 128 x 128 (default) or the round-2 8 waves of 128 x 64
-    const void* kern[2][3] = {
-        {reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_NONE, 2>),
-         reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_TENSOR, 2>),
-         reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_COUNTER, 2>)},
-        {reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_NONE, 4>),
-         reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_TENSOR, 4>),
-         reinterpret_cast<const void*>(big_step_kernel<TR, ESN_NOISE_COUNTER, 4>)}};
+    // main loop: 0 = round-2 (two 64-deep buffers, two barriers per chunk), 1 = round-3 pipeline (four 32-deep stages, DMA
+    // launches between the MFMAs, one barrier per stage; default), 2 = 4 waves of 128 x 128 (a kept negative result)
+    const int variant = knobs().big_nt == 4 ? 2 : (knobs().big_pipe ? 1 : 0);
     const int ni = rp.noise_mode == ESN_NOISE_NONE ? 0 : rp.noise_mode == ESN_NOISE_TENSOR ? 1 : 2;
-    e = hipFuncSetAttribute(kern[wide ? 1 : 0][ni], hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+#define ESN_BIG_K(NZ) {reinterpret_cast<const void*>(big_step_kernel<TR, NZ, 2, false>), \
+                       reinterpret_cast<const void*>(big_step_kernel<TR, NZ, 2, true>),  \
+                       reinterpret_cast<const void*>(big_step_kernel<TR, NZ, 4, false>)}
+    const void* kern[3][3] = {ESN_BIG_K(ESN_NOISE_NONE), ESN_BIG_K(ESN_NOISE_TENSOR), ESN_BIG_K(ESN_NOISE_COUNTER)};
+#undef ESN_BIG_K
+    e = hipFuncSetAttribute(kern[ni][variant], hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
     if (e != hipSuccess) return (int)e;
+    const dim3 block(variant == 2 ? 256 : 512);
     for (int s = 0; s <= rp.S; ++s) {
         // prep(s): partials of X_s (from GEMM s-1, in YP[s & 1]) -> Y row s-1; [U_s ; F_s] -> image X[s & 1]
         bp.step = s;
@@ -435,25 +488,9 @@ static int launch_big_t(const RecurParams& rp, size_t wo_big_off, void* workspac
         if (s == rp.S) break;
         bp.x_in = X[s & 1]; bp.x_out = X[(s + 1) & 1];
         bp.yp_out = YP[(s + 1) & 1];
-        if (wide) {
-            switch (rp.noise_mode) {
-                case ESN_NOISE_NONE:
-                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_NONE, 4>), grid, dim3(256), BIG_LDS, stream, bp); break;
-                case ESN_NOISE_TENSOR:
-                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_TENSOR, 4>), grid, dim3(256), BIG_LDS, stream, bp); break;
-                default:
-                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_COUNTER, 4>), grid, dim3(256), BIG_LDS, stream, bp); break;
-            }
-        } else {
-            switch (rp.noise_mode) {
-                case ESN_NOISE_NONE:
-                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_NONE, 2>), grid, dim3(512), BIG_LDS, stream, bp); break;
-                case ESN_NOISE_TENSOR:
-                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_TENSOR, 2>), grid, dim3(512), BIG_LDS, stream, bp); break;
-                default:
-                    hipLaunchKernelGGL((big_step_kernel<TR, ESN_NOISE_COUNTER, 2>), grid, dim3(512), BIG_LDS, stream, bp); break;
-            }
-        }
+        void* args[] = {&bp};
+        e = hipLaunchKernel(kern[ni][variant], grid, block, args, BIG_LDS, stream);
+        if (e != hipSuccess) return (int)e;
     }
     return (int)hipGetLastError();
 }
@@ -490,9 +527,10 @@ struct BigHarvestParams {
     const char* x_in;
     char* x_out;
 };
-constexpr int BH_NST = 4;                              // chunks in flight
+constexpr int BH_NST = 6;                              // stage buffers: BH_NST - 1 chunks in flight (the stream is bound by
+                                                       // bytes in flight x L2 latency: 4 buffers gave 38 GB/s per CU)
 constexpr int BH_STAGE = 24576;                        // A 16 KB + B 8 KB
-constexpr int BH_LDS = BH_NST * BH_STAGE;              // 96 KB (the epilogue's 33 KB transpose scratch aliases it)
+constexpr int BH_LDS = BH_NST * BH_STAGE;              // 144 KB (the epilogue's 33 KB transpose scratch aliases it)
 constexpr int BH_ELD = 132;                            // floats per pilot row of the transpose scratch (128 + pad)
 
 size_t big_harvest_workspace_bytes(int n_groups, int Kp) { return 2 * (size_t)round_up(n_groups, 64) * Kp * 2; }
@@ -649,14 +687,22 @@ __global__ __launch_bounds__(256) void bigh_step_kernel(BigHarvestParams hp) {
 #pragma unroll
     for (int c = 0; c < BH_NST - 1; ++c)
         if (c < nch) issue(c, c);
+    int buf = 0, buf_issue = BH_NST - 1;                       // c % BH_NST and (c + BH_NST - 1) % BH_NST
     for (int c = 0; c < nch; ++c) {
         // this wave's six pieces of chunk c have landed when at most the later chunks' are outstanding
-        if (c + 2 < nch) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int later = nch - 1 - c < BH_NST - 2 ? nch - 1 - c : BH_NST - 2;
+        switch (later) {
+            case 4: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
         __builtin_amdgcn_s_barrier();                          // everybody's pieces of chunk c; chunk c-1 read by all
-        if (c + BH_NST - 1 < nch) issue(c + BH_NST - 1, (c + BH_NST - 1) & (BH_NST - 1));
-        compute(c & (BH_NST - 1));
+        if (c + BH_NST - 1 < nch) issue(c + BH_NST - 1, buf_issue);
+        compute(buf);
+        buf = buf + 1 == BH_NST ? 0 : buf + 1;
+        buf_issue = buf_issue + 1 == BH_NST ? 0 : buf_issue + 1;
     }
     __syncthreads();                                           // stage buffers free: the transpose scratch aliases them
 
