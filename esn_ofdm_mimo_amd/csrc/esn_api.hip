@@ -367,7 +367,7 @@ size_t esn_harvest_workspace_bytes(int precision, const esn_shape_t* shape, int 
     if (fill_common(p, precision, shape, "esn_harvest_workspace_bytes", true)) return 0;
     p.harvest = 1; p.n_groups = n_groups; p.n_frames = n_groups;
     if (knobs().cluster && cluster_applies(precision, p)) return cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, true);
-    if (!p.g.big || !big_harvest_applies(precision, p)) return 0;
+    if (!big_harvest_applies(precision, p)) return 0;
     return big_harvest_workspace_bytes(n_groups, p.g.Kp);
 }
 
@@ -419,7 +419,7 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
         return hip_fail(launch_recur_cluster(p, workspace, (hipStream_t)stream), "esn_harvest_batch");
     }
     // large reservoirs: one GEMM launch per step when the caller lends a workspace (else the persistent kernel)
-    if (workspace && knobs().big_gemm && p.g.big && big_harvest_applies(precision, p)) {
+    if (workspace && knobs().big_gemm && big_harvest_applies(precision, p)) {
         const size_t need = big_harvest_workspace_bytes(n_groups, p.g.Kp);
         if (workspace_bytes < need)
             return fail(-1, "esn_harvest_batch: workspace holds %zu bytes, esn_harvest_workspace_bytes says %zu",

@@ -622,8 +622,13 @@ __global__ void bigh_fill_e_kernel(BigHarvestParams hp) {
     }
 }
 
-template <typename TR, int NOISE>
+// KGC = k-groups per chunk: 4 (64 deep) where Kp is a multiple of 64 (reservoirs beyond 1024 units), 2 (32 deep) for the
+// persistent kernels' images (Kp a multiple of 32: N_res = 512 has 34 k-groups)
+template <typename TR, int NOISE, int KGC>
 __global__ __launch_bounds__(256) void bigh_step_kernel(BigHarvestParams hp) {
+    constexpr int TILE_B = KGC * 1024;                   // one 32-row / 32-pilot operand tile of a chunk
+    constexpr int A_B = 4 * TILE_B, STAGE_B = 6 * TILE_B;
+    constexpr int PPC = KGC + KGC / 2;                   // DMA pieces per wave and chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RecurParams& p = hp.r;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -652,19 +657,19 @@ __global__ __launch_bounds__(256) void bigh_step_kernel(BigHarvestParams hp) {
     };
     const __amdgpu_buffer_rsrc_t a_rsrc = uniform_rsrc(p.packed_w, (int)p.wset_stride);
     const __amdgpu_buffer_rsrc_t b_rsrc = uniform_rsrc(hp.x_in, (int)x_bytes);
-    // per chunk: wave w fetches row tile w of A (4 k-groups) and half a pilot tile of B (2 k-groups)
+    // per chunk: wave w fetches row tile w of A (KGC k-groups) and half a pilot tile of B (KGC / 2 k-groups)
     const int a_src = (m * 4 + wave) * nkg;
-    const int b_src = ((slot0 >> 5) + wn) * nkg + 2 * wm;
+    const int b_src = ((slot0 >> 5) + wn) * nkg + (KGC / 2) * wm;
     auto issue = [&](int c, int buf) {
-        char* st = smem + (size_t)buf * BH_STAGE;
+        char* st = smem + (size_t)buf * STAGE_B;
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(st + (wave * 4 + kg) * 1024),
-                                                     16, lane16, (a_src + 4 * c + kg) * 1024, 0, 0);
+        for (int kg = 0; kg < KGC; ++kg)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(st + (wave * KGC + kg) * 1024),
+                                                     16, lane16, (a_src + KGC * c + kg) * 1024, 0, 0);
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(st + 16384 + (wn * 4 + 2 * wm + kg) * 1024),
-                                                     16, lane16, (b_src + 4 * c + kg) * 1024, 0, 0);
+        for (int kg = 0; kg < KGC / 2; ++kg)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(st + A_B + (wn * KGC + (KGC / 2) * wm + kg) * 1024),
+                                                     16, lane16, (b_src + KGC * c + kg) * 1024, 0, 0);
     };
     f32x16 acc[2];
 #pragma unroll
@@ -672,18 +677,18 @@ __global__ __launch_bounds__(256) void bigh_step_kernel(BigHarvestParams hp) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
     auto compute = [&](int buf) {
-        const char* ab = smem + (size_t)buf * BH_STAGE + (size_t)(wm * 2) * 4096 + lane16;
-        const char* bb = smem + (size_t)buf * BH_STAGE + 16384 + (size_t)wn * 4096 + lane16;
+        const char* ab = smem + (size_t)buf * STAGE_B + (size_t)(wm * 2) * TILE_B + lane16;
+        const char* bb = smem + (size_t)buf * STAGE_B + A_B + (size_t)wn * TILE_B + lane16;
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
+        for (int kg = 0; kg < KGC; ++kg) {
             const u32x4 b = *reinterpret_cast<const u32x4*>(bb + kg * 1024);
             const u32x4 a0 = *reinterpret_cast<const u32x4*>(ab + kg * 1024);
-            const u32x4 a1 = *reinterpret_cast<const u32x4*>(ab + 4096 + kg * 1024);
+            const u32x4 a1 = *reinterpret_cast<const u32x4*>(ab + TILE_B + kg * 1024);
             TR::mma32(acc[0], a0, b);
             TR::mma32(acc[1], a1, b);
         }
     };
-    const int nch = nkg / 4;
+    const int nch = nkg / KGC;
 #pragma unroll
     for (int c = 0; c < BH_NST - 1; ++c)
         if (c < nch) issue(c, c);
@@ -691,12 +696,23 @@ __global__ __launch_bounds__(256) void bigh_step_kernel(BigHarvestParams hp) {
     for (int c = 0; c < nch; ++c) {
         // this wave's six pieces of chunk c have landed when at most the later chunks' are outstanding
         const int later = nch - 1 - c < BH_NST - 2 ? nch - 1 - c : BH_NST - 2;
-        switch (later) {
-            case 4: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        static_assert(PPC == 6 || PPC == 3, "DMA pieces per wave and chunk");
+        if constexpr (PPC == 6) {
+            switch (later) {
+                case 4: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        } else {
+            switch (later) {
+                case 4: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
         }
         __builtin_amdgcn_s_barrier();                          // everybody's pieces of chunk c; chunk c-1 read by all
         if (c + BH_NST - 1 < nch) issue(c + BH_NST - 1, buf_issue);
@@ -802,30 +818,34 @@ static int launch_bigh_t(const RecurParams& rp, void* workspace, hipStream_t str
     hipLaunchKernelGGL(bigh_fill_e_kernel, dim3(1024), dim3(256), 0, stream, hp);
     const int n_ft = hp.n_slots / 64;
     const dim3 grid(hp.n_mt % 8 == 0 ? hp.n_mt * n_ft : 8 * ((n_ft + 7) / 8) * hp.n_mt);
-    const void* k_none = reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_NONE>);
-    const void* k_tens = reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_TENSOR>);
-    const void* k_cnt = reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_COUNTER>);
-    hipError_t e = hipFuncSetAttribute(rp.noise_mode == ESN_NOISE_NONE ? k_none : rp.noise_mode == ESN_NOISE_TENSOR ? k_tens : k_cnt,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, BH_LDS);
+    const bool deep = (Kp % 64) == 0;                      // 64-deep chunks where the image allows, else 32-deep
+    const int ni = rp.noise_mode == ESN_NOISE_NONE ? 0 : rp.noise_mode == ESN_NOISE_TENSOR ? 1 : 2;
+    const void* kern[2][3] = {
+        {reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_NONE, 2>),
+         reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_TENSOR, 2>),
+         reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_COUNTER, 2>)},
+        {reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_NONE, 4>),
+         reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_TENSOR, 4>),
+         reinterpret_cast<const void*>(bigh_step_kernel<TR, ESN_NOISE_COUNTER, 4>)}};
+    const void* kfn = kern[deep ? 1 : 0][ni];
+    const int lds = BH_LDS > 36 * 1024 ? BH_LDS : 36 * 1024;     // (the transpose scratch needs 33 KB whatever the stage size)
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     for (int s = 0; s < rp.S; ++s) {
         hp.step = s; hp.x_in = X[s & 1]; hp.x_out = X[(s + 1) & 1];
-        switch (rp.noise_mode) {
-            case ESN_NOISE_NONE:
-                hipLaunchKernelGGL((bigh_step_kernel<TR, ESN_NOISE_NONE>), grid, dim3(256), BH_LDS, stream, hp); break;
-            case ESN_NOISE_TENSOR:
-                hipLaunchKernelGGL((bigh_step_kernel<TR, ESN_NOISE_TENSOR>), grid, dim3(256), BH_LDS, stream, hp); break;
-            default:
-                hipLaunchKernelGGL((bigh_step_kernel<TR, ESN_NOISE_COUNTER>), grid, dim3(256), BH_LDS, stream, hp); break;
-        }
+        void* args[] = {&hp};
+        e = hipLaunchKernel(kfn, grid, dim3(256), args, lds, stream);
+        if (e != hipSuccess) return (int)e;
     }
     return (int)hipGetLastError();
 }
 
 // shapes the harvest GEMM serves: fp16/bf16, shared reservoir, reservoirs beyond 1024 units
 bool big_harvest_applies(int precision, const RecurParams& p) {
-    return (precision == ESN_F16 || precision == ESN_BF16) && p.harvest && p.n_wsets == 1 && p.n_res > 1024 &&
-           p.n_in <= 16 && p.n_out <= 8 && p.g.Mp % 128 == 0 && p.g.Kp % 64 == 0 && p.g.Kp / 64 >= BH_NST &&
+    // (reservoirs of 257..1024 units: from 64 pilots on -- 137 launches are not worth it for a handful of sequences)
+    return (precision == ESN_F16 || precision == ESN_BF16) && p.harvest && p.n_wsets == 1 &&
+           (p.n_res > 1024 || (p.n_res > 256 && p.n_groups >= 64)) &&
+           p.n_in <= 16 && p.n_out <= 8 && p.g.Mp % 128 == 0 && p.g.Kp % 32 == 0 && p.g.Kp / 64 >= BH_NST &&
            p.g.Kp - p.g.Mp >= 32 && p.g.kfb - p.g.kin + round_up(p.n_out, 4) <= 32 &&
            (size_t)round_up(p.n_groups, 64) * p.g.Kp * 2 < 0x7fffffffu && p.wset_stride < 0x7fffffffu;
 }

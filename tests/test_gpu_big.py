@@ -98,7 +98,10 @@ def test_big_gemm_single_frame_and_no_workspace(mods):
 
 
 @pytest.mark.parametrize("n_res,n_in,n_out,G,precision,e_dtype", [(2048, 16, 8, 70, "f16", "f32"), (2048, 16, 8, 5, "f16", "f64"),
-                                                                 (1500, 4, 4, 129, "f16", "f32"), (2048, 16, 8, 33, "bf16", "f32")])
+                                                                 (1500, 4, 4, 129, "f16", "f32"), (2048, 16, 8, 33, "bf16", "f32"),
+                                                                 # 257..1024 units, 64 pilots or more: the same GEMM with 32-deep chunks
+                                                                 (512, 16, 8, 70, "f16", "f32"), (300, 16, 8, 64, "f16", "f64"),
+                                                                 (1024, 8, 4, 65, "bf16", "f32")])
 @pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3), ("tensor", 1e-3)])
 def test_big_gemm_harvest_matches_persistent_kernel(mods, n_res, n_in, n_out, G, precision, e_dtype, noise_mode, noise):
     """Teacher-forced harvest as one 128 x 64-tiled GEMM launch per step (bigh_step_kernel) against the persistent
