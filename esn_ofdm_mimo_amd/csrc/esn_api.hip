@@ -101,6 +101,8 @@ Knobs& knobs() {
         v = getenv("ESN_CLUSTER");
         x.cluster = (v && v[0] == '0') ? 0 : 1;
         x.gen_ko = 0;
+        v = getenv("ESN_HARVEST_GEMM");
+        x.harvest_gemm = (v && v[0] == '1') ? 1 : 0;
         v = getenv("ESN_BIG_NT");
         x.big_nt = (v && v[0] == '4') ? 4 : 2;
         v = getenv("ESN_BIG_PIPE");
@@ -182,6 +184,7 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "big_gemm")) { k.big_gemm = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "cluster")) { k.cluster = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "gen_ko")) { k.gen_ko = value ? atoi(value) : 0; return 0; }
+    if (!strcmp(key, "harvest_gemm")) { k.harvest_gemm = (value && value[0] == '1') ? 1 : 0; return 0; }
     if (!strcmp(key, "big_nt")) { k.big_nt = (value && value[0] == '4') ? 4 : 2; return 0; }
     if (!strcmp(key, "big_pipe")) { k.big_pipe = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);

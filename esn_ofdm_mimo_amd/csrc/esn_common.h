@@ -201,6 +201,7 @@ struct Knobs {
     int cluster;           // 1 (default): ONE float64 sequence runs on the LDS-resident cluster kernel when a workspace is given
     int big_nt;            // N_res > 1024 predict: 4 = the 4-wave 128 x 128 variant of big_step_kernel (slower: A/B only); default 2
     int big_pipe;          // 1 (default): big_step_kernel's four-stage pipelined main loop; 0: the round-2 loop (A/B runs)
+    int harvest_gemm;      // 1: harvests of 257..1024 units (>= 64 pilots) also take the GEMM-per-step path (A/B; slower)
     int gen_ko;            // frame generator knock-out mask for tools/time_gen.py (timing only, wrong frames)
 };
 Knobs& knobs();

@@ -842,9 +842,11 @@ static int launch_bigh_t(const RecurParams& rp, void* workspace, hipStream_t str
 
 // shapes the harvest GEMM serves: fp16/bf16, shared reservoir, reservoirs beyond 1024 units
 bool big_harvest_applies(int precision, const RecurParams& p) {
-    // (reservoirs of 257..1024 units: from 64 pilots on -- 137 launches are not worth it for a handful of sequences)
+    // (Reservoirs of 257..1024 units can run here too -- 32-deep chunks, KGC = 2; debug knob "harvest_gemm" -- and were
+    //  measured at N_res = 512, 2048 pilots: 137 launches of 128 workgroups took ~1.8 ms against 1.16 ms for the persistent
+    //  kernel's 64 workgroups; the launch chain, not the tile, is the cost.  Off by default.)
     return (precision == ESN_F16 || precision == ESN_BF16) && p.harvest && p.n_wsets == 1 &&
-           (p.n_res > 1024 || (p.n_res > 256 && p.n_groups >= 64)) &&
+           (p.n_res > 1024 || (knobs().harvest_gemm && p.n_res > 256 && p.n_groups >= 64)) &&
            p.n_in <= 16 && p.n_out <= 8 && p.g.Mp % 128 == 0 && p.g.Kp % 32 == 0 && p.g.Kp / 64 >= BH_NST &&
            p.g.Kp - p.g.Mp >= 32 && p.g.kfb - p.g.kin + round_up(p.n_out, 4) <= 32 &&
            (size_t)round_up(p.n_groups, 64) * p.g.Kp * 2 < 0x7fffffffu && p.wset_stride < 0x7fffffffu;

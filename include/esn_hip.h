@@ -89,6 +89,10 @@ int esn_abi_version(void);
  *                   the product library answers -3) instead of the skewed LDS-state kernel
  *   "big_gemm"      "0" = N_res > 1024 predict on the persistent kernel even when a workspace is given
  *   "cluster"       "0" = a single float64 sequence on the vector-ALU kernel even when a workspace is given
+ *   "big_pipe"      "0" = N_res > 1024 predict with the round-2 main loop (two buffers, two barriers per chunk)
+ *   "big_nt"        "4" = N_res > 1024 predict on the 4-wave 128 x 128 variant (slower; A/B runs)
+ *   "harvest_gemm"  "1" = harvests of 257..1024 units (>= 64 pilots) on the GEMM-per-step path (slower; A/B runs)
+ *   "gen_ko"        frame-generator knock-out mask for tools/time_gen.py (timing only, wrong frames)
  * Returns 0, or -1 for an unknown key. */
 int esn_debug_set(const char* key, const char* value);
 

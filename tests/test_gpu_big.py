@@ -99,7 +99,7 @@ def test_big_gemm_single_frame_and_no_workspace(mods):
 
 @pytest.mark.parametrize("n_res,n_in,n_out,G,precision,e_dtype", [(2048, 16, 8, 70, "f16", "f32"), (2048, 16, 8, 5, "f16", "f64"),
                                                                  (1500, 4, 4, 129, "f16", "f32"), (2048, 16, 8, 33, "bf16", "f32"),
-                                                                 # 257..1024 units, 64 pilots or more: the same GEMM with 32-deep chunks
+                                                                 # 257..1024 units, 64 pilots or more: the same GEMM with 32-deep chunks (debug knob harvest_gemm)
                                                                  (512, 16, 8, 70, "f16", "f32"), (300, 16, 8, 64, "f16", "f64"),
                                                                  (1024, 8, 4, 65, "bf16", "f32")])
 @pytest.mark.parametrize("noise_mode,noise", [("none", 0.0), ("counter", 1e-3), ("tensor", 1e-3)])
@@ -122,8 +122,12 @@ def test_big_gemm_harvest_matches_persistent_kernel(mods, n_res, n_in, n_out, G,
         kw["noise_u"] = rs.rand(G, t - 1, n_res)
     from esn_ofdm_mimo_amd._lib import PRECISIONS
     import ctypes as C
-    assert lib.load().esn_harvest_workspace_bytes(PRECISIONS[precision], C.byref(bank.shape), G) > 0
-    big = bank.harvest(u, d, **kw).double().cpu().numpy()
+    lib.debug_set("harvest_gemm", "1")          # (reservoirs of 257..1024 units take the GEMM path only on request: it is slower)
+    try:
+        assert lib.load().esn_harvest_workspace_bytes(PRECISIONS[precision], C.byref(bank.shape), G) > 0
+        big = bank.harvest(u, d, **kw).double().cpu().numpy()
+    finally:
+        lib.debug_set("harvest_gemm", "0")
     lib.debug_set("big_gemm", "0")
     try:
         persistent = bank.harvest(u, d, **kw).double().cpu().numpy()
