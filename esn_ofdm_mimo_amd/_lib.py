@@ -83,6 +83,13 @@ def load():
         raise EsnHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the ESN hot path.")
+    # torch first: libesn_hip.so must resolve libamdhip64 to the copy torch has already loaded -- loaded before torch it
+    # binds the system ROCm runtime instead, the process ends up with two HIP runtimes and every launch of this
+    # library fails with hipErrorNoDevice (seen with build() + smoke() in one process)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
