@@ -22,6 +22,9 @@ Cases:
          (BASELINE configs[0]; the series comes from oracle/mackey_glass.py and is stored)
   scan   N_res=100  2x2   N=128  trainMIMOESN_generic with DelayFlag=1 (delay scan, helper:66-81)
   legacy N_res=100  2x2   N=128  HelpFunc.trainMIMOESN (7 fit+predict, forced d=3; HelpFunc.py:64-187)
+  driver_funcs  the top-level functions of the reference's driver SCRIPTS (hard-bit decision, per-tone MMSE/ZF
+         equalisers, LLR demapper, TDL-B taps, logistic-regression detector, encoder): the scripts run a whole sweep
+         at import, so only their `def`s (and the `_TDLB_*` tables) are compiled, via `ast` (driver_functions())
 """
 import hashlib
 import os
