@@ -9,7 +9,8 @@ LIB_PATH = os.environ.get("ESN_HIP_LIB") or os.path.join(_PKG, "libesn_hip.so") 
 F64, F32, F16, BF16 = 0, 1, 2, 3
 PRECISIONS = {"f64": F64, "f32": F32, "f16": F16, "bf16": BF16}
 NOISE_NONE, NOISE_TENSOR, NOISE_COUNTER = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
+MEM_DEVICE, MEM_HOST = 0, 1
 
 
 class Shape(C.Structure):
@@ -70,6 +71,12 @@ SIGNATURES = {
     "esn_detect_count": (C.c_int, [_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _vp,
                                    _vp, _vp, _dp, _vp]),
 }
+# host-memory front ends: the arguments of esn_X behind a leading esn_mem_kind (include/esn_hip.h)
+for _name in ("esn_pack_weights", "esn_pack_readout", "esn_predict_batch", "esn_harvest_batch",
+              "esn_readout_solve_batch", "esn_detect_count"):
+    SIGNATURES[_name + "_mem"] = (C.c_int, [C.c_int] + SIGNATURES[_name][1])
+SIGNATURES["esn_device_alloc"] = (C.c_void_p, [C.c_size_t])
+SIGNATURES["esn_device_free"] = (C.c_int, [C.c_void_p])
 
 _lib = None
 

@@ -121,6 +121,17 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace esn {
+// for esn_host.hip: same error string, same conventions
+int api_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace esn
+
 static int hip_fail(int e, const char* what) {
     if (e == 0) return 0;
     if (e > 0) return fail(-1000 - e, "%s: HIP error %d (%s)", what, e, hipGetErrorString((hipError_t)e));
@@ -163,7 +174,7 @@ extern "C" {
 
 const char* esn_last_error(void) { return g_err; }
 
-int esn_abi_version(void) { return 7; }
+int esn_abi_version(void) { return 8; }
 
 int esn_debug_set(const char* key, const char* value) {
     if (!key) return fail(-1, "esn_debug_set: null key");

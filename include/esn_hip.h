@@ -6,8 +6,8 @@
  * on the caller's hipStream_t (passed as void*; NULL = default stream).  No
  * hidden global state besides a thread-local error string and the tuning knobs
  * of esn_debug_set (below; never needed by a user); no exceptions cross
- * the boundary.  All array arguments are DEVICE pointers unless a name ends in
- * `_host`.  Arrays keep the reference's own row-major float64 layouts so a
+ * the boundary.  All array arguments are DEVICE pointers, except in the `esn_*_mem` entry points
+ * called with ESN_MEM_HOST (below).  Arrays keep the reference's own row-major float64 layouts so a
  * binding needs no repacking:
  *
  *   inputs   U  [B][T_in][n_in]     (== complex128 [B][T_in][N_r] viewed as float64
@@ -243,6 +243,59 @@ int esn_detect_count(const double* Y, int n_frames, int frames_per_group,
                      const double* p_i, const uint8_t* tx_bits,
                      long long* err_count, long long* bit_count,
                      double* X_hat, void* stream);
+
+/* ---- Host-memory front ends ("caller-owned device or host pointers flagged by an enum").
+ * The reference's callers hold C-contiguous float64 NumPy arrays on the host (pyESN.py:154,218); a binding that
+ * lives there passes them as they are with ESN_MEM_HOST.  Each `esn_X_mem(mem_kind, ...)` takes the arguments
+ * of `esn_X(...)`:
+ *   ESN_MEM_DEVICE  forwards to esn_X unchanged (asynchronous on `stream`, no allocation).
+ *   ESN_MEM_HOST    every ARRAY argument (weights, scalings, U, D, x0, y0, noise_u, Y, E, W_out, status, p_i,
+ *                   tx_bits, counters, X_hat) is host memory: the call stages it in device memory from the
+ *                   stream-ordered pool, runs esn_X on `stream`, copies the results back and returns after
+ *                   the stream has drained, so the host arrays are complete on return.  The counters of
+ *                   esn_detect_count_mem are read, added to and written back.
+ * `packed` images and `workspace` are device memory in both kinds -- esn_device_alloc / esn_device_free hand
+ * them to a caller that has no HIP toolchain of its own (sizes from esn_packed_*_bytes / esn_*_workspace_bytes;
+ * esn_readout_solve_batch_mem takes its scratch from the pool when `workspace` is NULL).
+ * Returns as esn_X; -1 for an unknown mem_kind. */
+enum esn_mem_kind {
+    ESN_MEM_DEVICE = 0,
+    ESN_MEM_HOST = 1
+};
+void* esn_device_alloc(size_t bytes);   /* NULL on failure (esn_last_error()) */
+int esn_device_free(void* p);
+int esn_pack_weights_mem(int mem_kind, int precision, const esn_shape_t* shape,
+                         const double* W, const double* W_in, const double* W_fb,
+                         void* packed, void* stream);
+int esn_pack_readout_mem(int mem_kind, int precision, const esn_shape_t* shape, int n_groups,
+                         const double* W_out, void* packed, void* stream);
+int esn_predict_batch_mem(int mem_kind, int precision, const esn_shape_t* shape,
+                          const void* packed_w, const void* packed_wout,
+                          const double* in_scale, const double* in_shift,
+                          const double* t_scale, const double* t_shift,
+                          const double* U, int n_frames, int frames_per_group,
+                          int T_in, int T, int transient,
+                          const double* x0, const double* y0,
+                          double noise, int noise_mode, const double* noise_u,
+                          uint64_t seed, uint64_t group_offset,
+                          double* Y, void* workspace, size_t workspace_bytes, void* stream);
+int esn_harvest_batch_mem(int mem_kind, int precision, const esn_shape_t* shape,
+                          const void* packed_w,
+                          const double* in_scale, const double* in_shift,
+                          const double* t_scale, const double* t_shift,
+                          const double* U, const double* D, int n_groups, int T,
+                          double noise, int noise_mode, const double* noise_u,
+                          uint64_t seed, uint64_t group_offset, double* E,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int esn_readout_solve_batch_mem(int mem_kind, const double* E, const double* D, int n_groups, int T,
+                                int transient, int cols, int n_out,
+                                const double* t_scale, const double* t_shift,
+                                double* W_out, int* status, void* workspace, void* stream);
+int esn_detect_count_mem(int mem_kind, const double* Y, int n_frames, int frames_per_group,
+                         int n_sub, int n_t, int bits_per_sym,
+                         const double* p_i, const uint8_t* tx_bits,
+                         long long* err_count, long long* bit_count,
+                         double* X_hat, void* stream);
 
 /* ---- Monte-Carlo frame generator: the producer directly upstream of the detector.
  * float64 / complex128 like the reference; counter-based random streams keyed by

@@ -25,6 +25,12 @@ int main(void) {
     if (esn_detect_count(0, 1, 1, 128, 4, 4, 0, 0, 0, 0, 0, 0) != -1) return 7;
     if (esn_gen_frames(1, 1, 100, 7, 4, 8, 8, 4, 0, (const double*)1, (const double*)1, 1e-5, (const double*)1,
                        0, 0, 0, 0, (uint8_t*)1, 0, (double*)1, 0) != -1) return 8;   /* N not a power of two */
+    /* the host-memory front ends validate before they stage anything */
+    if (esn_predict_batch_mem(2, ESN_F64, &sh, 0, 0, 0, 0, 0, 0, 0, 1, 1, 4, 4, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0) != -1)
+        return 9;
+    if (!strstr(esn_last_error(), "memory kind")) return 10;
+    if (esn_detect_count_mem(ESN_MEM_HOST, 0, 1, 1, 128, 4, 4, 0, 0, 0, 0, 0, 0) != -1) return 11;
+    if (esn_device_free(0) != 0) return 12;
     printf("abi %d ok\n", esn_abi_version());
     return 0;
 }
