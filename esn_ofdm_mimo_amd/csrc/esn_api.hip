@@ -35,6 +35,8 @@ int launch_recur_cluster(const RecurParams& p, void* workspace, hipStream_t stre
 // esn_recur_mfma.hip
 bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
+// esn_recur_skew16.hip
+int launch_recur_skew16(int precision, const RecurParams& p, hipStream_t stream);
 // esn_pack.hip
 size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
 size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g);
@@ -105,6 +107,8 @@ Knobs& knobs() {
         x.harvest_gemm = (v && v[0] == '1') ? 1 : 0;
         v = getenv("ESN_BIG_NT");
         x.big_nt = (v && v[0] == '4') ? 4 : 2;
+        v = getenv("ESN_S16");
+        x.s16 = (v && v[0] == '0') ? 0 : 1;
         v = getenv("ESN_BIG_PIPE");
         x.big_pipe = (v && v[0] == '0') ? 0 : 1;
         return x;
@@ -197,6 +201,7 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "gen_ko")) { k.gen_ko = value ? atoi(value) : 0; return 0; }
     if (!strcmp(key, "harvest_gemm")) { k.harvest_gemm = (value && value[0] == '1') ? 1 : 0; return 0; }
     if (!strcmp(key, "big_nt")) { k.big_nt = (value && value[0] == '4') ? 4 : 2; return 0; }
+    if (!strcmp(key, "s16")) { k.s16 = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "big_pipe")) { k.big_pipe = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
 }
@@ -281,6 +286,8 @@ static int fill_common(RecurParams& p, int precision, const esn_shape_t* shape, 
     p.n_wsets = shape->n_wsets;
     p.wset_stride = packed_w_bytes(precision, p.n_res, p.n_in, p.n_out, p.g);
     p.wout_stride = packed_wout_bytes(precision, p.n_res, p.n_in, p.n_out, p.g);
+    p.w16_off = (size_t)p.g.Mp * p.g.Kp * 2;
+    p.wo16_off = wout_big_offset(precision, p.n_out, p.g);
     p.w64_off = f64_w_offset(p.n_res, p.n_in, p.n_out);
     p.wo64_off = f64_wout_offset(p.n_res, p.n_in, p.n_out);
     return 0;
@@ -358,6 +365,9 @@ int esn_predict_batch(int precision, const esn_shape_t* shape, const void* packe
         return hip_fail(launch_recur_rs(precision, p, wout_big_offset(precision, p.n_out, p.g), (hipStream_t)stream),
                         "esn_predict_batch");
 #endif
+    // N_res 257..512, fp16/bf16: the skewed schedule on 16x16x32 MFMAs (the chip holds a higher clock on that shape)
+    if (p.g.s16 && p.g.skew && knobs().s16 && (precision == ESN_F16 || precision == ESN_BF16))
+        return hip_fail(launch_recur_skew16(precision, p, (hipStream_t)stream), "esn_predict_batch");
     int e = m64 ? launch_recur_f64_mfma(p, (hipStream_t)stream)
             : (precision == ESN_F64) ? launch_recur_f64(p, (hipStream_t)stream)
                                      : launch_recur_mfma(precision, p, (hipStream_t)stream);

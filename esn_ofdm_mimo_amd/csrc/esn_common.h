@@ -26,6 +26,8 @@ struct Geometry {
                      // the packed read-out then carries that path's image behind the persistent kernel's
     int rs;          // fp16/bf16: the register-resident-state kernel (esn_recur_rs.hip) serves this shape; the packed
                      // read-out then carries that kernel's image behind the persistent kernel's
+    int s16;         // fp16/bf16: the 16x16x32 skewed predict kernel (esn_recur_skew16_impl.h) serves this shape; the
+                     // packed weights and read-out then carry that kernel's images behind the 32x32x16 ones
     int m64;         // ESN_F64: 1 = the float64 matrix-pipe kernel (esn_recur_f64_mfma.hip) fits this shape;
     int Bt64;        //          then Mp..Ks, MT, NT describe ITS tiling, Bt64 its frames per tile and Bt
                      //          stays the tile of the vector-ALU kernel (esn_recur_f64.hip)
@@ -55,6 +57,7 @@ struct RecurParams {
     const void* packed_w;   size_t wset_stride;   // bytes per weight set
     const void* packed_wout; size_t wout_stride;  // bytes per group
     size_t w64_off, wo64_off;                     // ESN_F64 images: byte offset of the MFMA-ordered copy
+    size_t w16_off, wo16_off;                     // g.s16: byte offset of the 16x16x32 kernel's images
     const double* in_scale; const double* in_shift;
     const double* t_scale;  const double* t_shift;
     const double* U; const double* D;
@@ -185,6 +188,16 @@ __device__ __forceinline__ int slot_frame(const RecurParams& p, int slot, int& g
 
 inline __host__ __device__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// k order of the 16x16x32 skewed kernel (esn_recur_skew16_impl.h): position of natural column k inside the padded
+// K axis.  State rows: R = 32 kk + 16 t + 4 g + e  ->  32 kk + 8 g + 4 t + e (the accumulator rows 4 g .. 4 g + 3 of two
+// row tiles form one 16-byte chunk of the next step's B operand); the [U ; F] group (k >= 512) keeps natural order.
+inline __host__ __device__ int s16_pos(int k) {
+    return k < 512 ? (k & ~31) + 8 * ((k & 15) >> 2) + 4 * ((k & 31) >> 4) + (k & 3) : k;
+}
+inline __host__ __device__ int s16_nat(int pos) {       // inverse of s16_pos
+    return pos < 512 ? (pos & ~31) + 16 * ((pos & 7) >> 2) + 4 * ((pos & 31) >> 3) + (pos & 3) : pos;
+}
+
 // Tuning / diagnostic knobs (benchmarks and A/B tests only).  Read ONCE per process from the
 // environment (ESN_SKEW, ESN_MFMA_GEOM, ESN_MFMA_GEOM_F32, ESN_CHOL_SKIP) and changed afterwards only
 // through the debug entry point esn_debug_set (esn_api.hip) -- never re-read per launch.  None of
@@ -203,6 +216,7 @@ struct Knobs {
     int big_pipe;          // 1 (default): big_step_kernel's four-stage pipelined main loop; 0: the round-2 loop (A/B runs)
     int harvest_gemm;      // 1: harvests of 257..1024 units (>= 64 pilots) also take the GEMM-per-step path (A/B; slower)
     int gen_ko;            // frame generator knock-out mask for tools/time_gen.py (timing only, wrong frames)
+    int s16;               // 1 (default): fp16/bf16 predict at 257..512 units on the 16x16x32 kernel; 0: the 32x32x16 one (A/B)
 };
 Knobs& knobs();
 

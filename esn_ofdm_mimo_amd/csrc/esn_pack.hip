@@ -87,7 +87,7 @@ __global__ void pack_wout_f64_mfma_kernel(const double* Wout, int n_res, int n_i
 template <typename T>
 __global__ void pack_w_mfma_kernel(const double* W, const double* Win, const double* Wfb,
                                    int n_res, int n_in, int n_out, int tf, int n_wsets,
-                                   Geometry g, T* out) {
+                                   Geometry g, size_t set_stride_bytes, char* out_base) {
     constexpr int ES = sizeof(T);
     constexpr int EPL = 16 / ES;                       // elements per lane per group
     const int nkg = g.Kp * ES / 32;
@@ -105,7 +105,33 @@ __global__ void pack_w_mfma_kernel(const double* W, const double* Win, const dou
                         Wfb + ws * (size_t)n_res * n_out, n_res, n_in, n_out, tf, g.kin, g.kfb, row, k);
         // fp16/bf16 kernels evaluate tanh from 2^z: fold 2 log2(e) into the weights (esn_common.h)
         if (ES == 2) v *= ACT_PRESCALE;
-        out[i] = (T)(float)v;
+        reinterpret_cast<T*>(out_base + ws * set_stride_bytes)[i % per] = (T)(float)v;
+    }
+}
+
+// Image of the 16x16x32 skewed predict kernel (esn_recur_skew16_impl.h), behind the 32x32x16 image of each set:
+// fragment (wave w, 32-k group kk, row tile m) at ((w NKK + kk) 4 + m) KB -- the 4 KB a wave needs per group are
+// contiguous; lane (r = lane & 15, q = lane >> 4) holds W[64 w + 16 m + r][s16_nat(32 kk + 8 q + e)], e = 0..7.
+template <typename T>
+__global__ void pack_w_s16_kernel(const double* W, const double* Win, const double* Wfb,
+                                  int n_res, int n_in, int n_out, int tf, int n_wsets,
+                                  Geometry g, size_t set_stride_bytes, size_t off_bytes, char* out_base) {
+    const int nkk = g.Kp / 32;
+    const size_t per = (size_t)g.Mp * g.Kp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per * n_wsets;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t ws = i / per, j = i % per;
+        const int e = (int)(j & 7); j >>= 3;
+        const int lane = (int)(j & 63); j >>= 6;
+        const int m = (int)(j & 3); j >>= 2;
+        const int kk = (int)(j % nkk);
+        const int w = (int)(j / nkk);
+        const int row = 64 * w + 16 * m + (lane & 15);
+        const int k = s16_nat(32 * kk + 8 * (lane >> 4) + e);
+        double v = wext(W + ws * (size_t)n_res * n_res, Win + ws * (size_t)n_res * n_in,
+                        Wfb + ws * (size_t)n_res * n_out, n_res, n_in, n_out, tf, g.kin, g.kfb, row, k);
+        v *= ACT_PRESCALE;
+        reinterpret_cast<T*>(out_base + ws * set_stride_bytes + off_bytes)[i % per] = (T)(float)v;
     }
 }
 
@@ -177,6 +203,30 @@ __global__ __launch_bounds__(256) void pack_wout_mfma_kernel(const double* Wout,
         float* tr = reinterpret_cast<float*>(out + g.ro_parts * per_part * ES);
         tr[0] = (float)(1.0 / gain); tr[1] = (float)gain; tr[2] = 0.f; tr[3] = 0.f;
     }
+    if (ES == 2 && g.s16) {
+        // image of the 16x16x32 skewed kernel: [32-k group kk][lane (o = lane & 15, q)][8 elements] in ITS k order
+        // (s16_nat), rows 0-7 hi, 8-15 the rounding residual; trailer {1/gain, gain, 0, 0}
+        char* sb = out + (packed_wout_persistent_bytes(ES, n_out, g) + 15) / 16 * 16;
+        T* simg = reinterpret_cast<T*>(sb);
+        const int nkk = g.Kp / 32;
+        for (int i = threadIdx.x; i < nkk * 512; i += blockDim.x) {
+            const int e = i & 7, lane = (i >> 3) & 63, kk = i >> 9;
+            const int o = lane & 15, oo = o & 7;
+            const int k = s16_nat(32 * kk + 8 * (lane >> 4) + e);
+            double v = 0.0;
+            if (oo < n_out) {
+                if (k < n_res) v = wo[(size_t)oo * ncols + k] * gain;
+                else if (k >= g.kin && k < g.kin + n_in) v = wo[(size_t)oo * ncols + n_res + (k - g.kin)] * gain;
+            }
+            const T hi = (T)(float)v;
+            const T lo = (T)(float)(v - (double)(float)hi);
+            simg[i] = o < 8 ? hi : lo;
+        }
+        if (threadIdx.x == 0) {
+            float* tr = reinterpret_cast<float*>(sb + (size_t)nkk * 1024);
+            tr[0] = (float)(1.0 / gain); tr[1] = (float)gain; tr[2] = 0.f; tr[3] = 0.f;
+        }
+    }
     if (ES == 2 && g.rs) {
         // image of the register-resident-state kernel (esn_recur_rs.hip): A operand of the 32x32x16 MFMA,
         // [k-group of 16][lane (row = lane & 31, h)][8 elements], k = 16 kg + 8 h + e natural; rows 0-7 hi, 8-15 lo
@@ -240,7 +290,7 @@ size_t packed_w_bytes(int precision, int n_res, int n_in, int n_out, const Geome
     if (precision == ESN_F64)
         return f64_w_offset(n_res, n_in, n_out) + (g.m64 ? sizeof(double) * (size_t)g.Mp * g.Kp : 0);
     const int es = (precision == ESN_F32) ? 4 : 2;
-    return (size_t)g.Mp * g.Kp * es;
+    return (size_t)g.Mp * g.Kp * es * (g.s16 ? 2 : 1);        // (+ the 16x16x32 kernel's copy)
 }
 
 size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Geometry& g) {
@@ -249,6 +299,7 @@ size_t packed_wout_bytes(int precision, int n_res, int n_in, int n_out, const Ge
     const int es = (precision == ESN_F32) ? 4 : 2;
     const size_t base = packed_wout_persistent_bytes(es, n_out, g);
     if (g.rs) return (base + 15) / 16 * 16 + rs_wout_image_bytes(g.Kp);
+    if (g.s16) return (base + 15) / 16 * 16 + (size_t)(g.Kp / 32) * 1024 + 16;
     return g.big ? (base + 15) / 16 * 16 + big_wout_image_bytes(g.Mp) : base;
 }
 size_t wout_big_offset(int precision, int n_out, const Geometry& g) {
@@ -258,6 +309,7 @@ size_t wout_big_offset(int precision, int n_out, const Geometry& g) {
 int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g, const double* W,
                         const double* Win, const double* Wfb, void* packed, hipStream_t stream) {
     const int blocks = 1024, threads = 256;
+    const size_t mstride = packed_w_bytes(precision, sh->n_res, sh->n_in, sh->n_out, g);
     if (precision == ESN_F64) {
         const size_t stride = packed_w_bytes(precision, sh->n_res, sh->n_in, sh->n_out, g);
         hipLaunchKernelGGL(pack_w_f64_kernel, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
@@ -269,16 +321,24 @@ int launch_pack_weights(int precision, const esn_shape_t* sh, const Geometry& g,
                                f64_w_offset(sh->n_res, sh->n_in, sh->n_out), reinterpret_cast<char*>(packed));
     } else if (precision == ESN_F32) {
         hipLaunchKernelGGL(pack_w_mfma_kernel<float>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
-                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g,
-                           reinterpret_cast<float*>(packed));
+                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g, mstride,
+                           reinterpret_cast<char*>(packed));
     } else if (precision == ESN_F16) {
         hipLaunchKernelGGL(pack_w_mfma_kernel<_Float16>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
-                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g,
-                           reinterpret_cast<_Float16*>(packed));
+                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g, mstride,
+                           reinterpret_cast<char*>(packed));
+        if (g.s16)
+            hipLaunchKernelGGL(pack_w_s16_kernel<_Float16>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
+                               sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g, mstride,
+                               (size_t)g.Mp * g.Kp * 2, reinterpret_cast<char*>(packed));
     } else if (precision == ESN_BF16) {
         hipLaunchKernelGGL(pack_w_mfma_kernel<__bf16>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
-                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g,
-                           reinterpret_cast<__bf16*>(packed));
+                           sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g, mstride,
+                           reinterpret_cast<char*>(packed));
+        if (g.s16)
+            hipLaunchKernelGGL(pack_w_s16_kernel<__bf16>, dim3(blocks), dim3(threads), 0, stream, W, Win, Wfb,
+                               sh->n_res, sh->n_in, sh->n_out, sh->teacher_forcing, sh->n_wsets, g, mstride,
+                               (size_t)g.Mp * g.Kp * 2, reinterpret_cast<char*>(packed));
     } else {
         return -1;
     }

@@ -52,6 +52,10 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
 #else
     g->rs = 0;      // the register-state kernel (and its read-out image) exist only in ESN_WITH_RS=1 builds
 #endif
+    // the 16x16x32 skewed predict kernel (esn_recur_skew16_impl.h): a function of the shape alone -- pack, harvest and
+    // predict agree on the images whatever the knobs say
+    g->s16 = (es == 2 && g->Mp == 512 && g->Kp == 544 && n_out <= 8 && !g->rs &&
+              (n_in == 2 || n_in == 4 || n_in == 8 || n_in == 16)) ? 1 : 0;
     g->big = (es == 2 && n_res > 1024 && n_in <= 16 && n_out <= 8 && g->Mp % 256 == 0 && g->Mp <= 2048 &&
               g->kfb - g->kin + round_up(n_out, 4) <= 32) ? 1 : 0;
     // row stride: an odd number of 16-byte slots -> conflict-free b128 column reads

@@ -101,6 +101,10 @@ struct TraitsF16 {
         typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
         *reinterpret_cast<h16x2v*>(dst) = h16x2v{(_Float16)v0, (_Float16)v1};
     }
+    static __device__ __forceinline__ uint32_t pack2(float v0, float v1) {
+        typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, h16x2v{(_Float16)v0, (_Float16)v1});
+    }
     static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const _Float16*>(src); }
     static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 8-byte aligned
         const h16x4 t = *reinterpret_cast<const h16x4*>(src);
@@ -131,6 +135,10 @@ struct TraitsBF16 {
     static __device__ __forceinline__ void store2(char* dst, float v0, float v1) {      // 4-byte aligned
         typedef __bf16 b16x2v __attribute__((ext_vector_type(2)));
         *reinterpret_cast<b16x2v*>(dst) = b16x2v{(__bf16)v0, (__bf16)v1};
+    }
+    static __device__ __forceinline__ uint32_t pack2(float v0, float v1) {
+        typedef __bf16 b16x2v __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, b16x2v{(__bf16)v0, (__bf16)v1});
     }
     static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const __bf16*>(src); }
     static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 8-byte aligned

@@ -47,12 +47,13 @@ def test_geometry_and_sizes(lib):
     assert lib.esn_packed_weights_bytes(F64, C.byref(sh)) == 8 * (512 + 16 + 8) * 512 + 8 * 512 * 536
     # MFMA images: Mp x Kp elements, Kp = roundup(512+16+8, 32) = 544
     assert lib.esn_packed_weights_bytes(F32, C.byref(sh)) == 4 * 512 * 544
-    assert lib.esn_packed_weights_bytes(F16, C.byref(sh)) == 2 * 512 * 544
-    assert lib.esn_packed_weights_bytes(BF16, C.byref(sh)) == 2 * 512 * 544
+    # fp16 / bf16 at 257..512 units: the 32x32x16 image (harvest, A/B runs) + the 16x16x32 kernel's copy behind it
+    assert lib.esn_packed_weights_bytes(F16, C.byref(sh)) == 2 * (2 * 512 * 544)
+    assert lib.esn_packed_weights_bytes(BF16, C.byref(sh)) == 2 * (2 * 512 * 544)
     assert lib.esn_packed_readout_bytes(F64, C.byref(sh)) == 8 * 8 * 528 + 8 * 16 * 536
     assert lib.esn_packed_readout_bytes(F32, C.byref(sh)) == 16 * 544 * 4 + 16
     # hi rows 0-7, lo rows 8-15 (the register-state kernel's image exists only in ESN_WITH_RS=1 experiment builds)
-    assert lib.esn_packed_readout_bytes(F16, C.byref(sh)) == 16 * 544 * 2 + 16
+    assert lib.esn_packed_readout_bytes(F16, C.byref(sh)) == (16 * 544 * 2 + 16) + (17 * 1024 + 16)
     assert lib.esn_packed_readout_bytes(F16, C.byref(Shape(256, 16, 8, 1, 1))) == 16 * 288 * 2 + 16
     small = Shape(100, 2, 2, 1, 1)
     assert lib.esn_tile_frames(F32, C.byref(small)) == 64

@@ -17,7 +17,7 @@ int main(void) {
     if (esn_abi_version() < 1) return 1;
     if (esn_tile_frames(ESN_F16, &sh) != 128) return 2;
     if (esn_tile_frames(ESN_F32, &sh) != 64) return 3;
-    if (esn_packed_weights_bytes(ESN_F16, &sh) != (size_t)2 * 512 * 544) return 4;
+    if (esn_packed_weights_bytes(ESN_F16, &sh) != (size_t)2 * 2 * 512 * 544) return 4;   /* two image cuts */
     sh.n_res = 0;
     if (esn_tile_frames(ESN_F64, &sh) >= 0) return 5;
     if (!strstr(esn_last_error(), "invalid shape")) return 6;

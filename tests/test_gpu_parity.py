@@ -199,6 +199,17 @@ def test_skewed_schedule_matches_in_step_schedule(amd, noise_mode, noise, n_res,
     finally:
         _lib.debug_set("skew", "1")
     assert skew.shape == plain.shape == (G * F - 9, t - tr, n_out)
+    # 257..512 units: the default is the 16x16x32 kernel (esn_recur_skew16_impl.h: its own weight / read-out images, k
+    # order and LDS layout); knob s16=0 selects the 32x32x16 skewed kernel on the same inputs and noise draws
+    _lib.debug_set("s16", "0")
+    try:
+        skew32 = bank.predict(u, F, **kw).cpu().numpy()
+    finally:
+        _lib.debug_set("s16", "1")
+    assert rel_err(skew, skew32) < (2e-3 if noise == 0.0 else 8e-3), rel_err(skew, skew32)
+    assert rel_err(skew32, plain) < (2e-3 if noise == 0.0 else 8e-3), rel_err(skew32, plain)
+    if 256 < n_res <= 512 and noise_mode == "counter":
+        assert not np.array_equal(skew, skew32)                      # (the knob did select another kernel)
     # same weights, same noise draws; only the summation order of the read-out and the rounding of
     # the noise addition (packed half: one more rounding to fp16 per state) differ
     assert rel_err(skew, plain) < (2e-3 if noise == 0.0 else 8e-3), rel_err(skew, plain)
