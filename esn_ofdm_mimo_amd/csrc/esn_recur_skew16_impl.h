@@ -211,7 +211,6 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
     };
     auto ro_prefetch = [&](int kk0, bool on) { load_ra(0, kk0, on); load_ra(1, kk0 + 1, on); };
     typedef const __attribute__((address_space(3))) u32x4* lds_frag_t;
-    const uint32_t zbase = (uint32_t)(uintptr_t)zf + (uint32_t)lane16;         // tile 0, group 0, this lane
     // State groups [kk0, kk0 + 8) out of abuf, two per trip; abuf[j] holds group kk0 + j on entry and kk0 + 8 + j on
     // exit.  B ring: slot n & 3 holds column tile n's fragment and is refilled behind that tile's four MFMAs with
     // tile n + 4's (n < 4: same group; else tile n - 4 of the next group) -- twelve MFMAs of look-ahead, 16 registers.
@@ -219,12 +218,18 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
     auto gemm_half = [&](int kk0, auto ro_tag, bool ro_on) {
         constexpr bool RO = decltype(ro_tag)::value;
         const int voff_ro = ro_on ? lane16 : OOB;      // (step 0 and tiles of padding: zero fragments, no traffic)
-        uint32_t bp0 = zbase + (uint32_t)kk0 * 1024;                            // tiles 0-3 / 4-7 of group kk0 + i
+        // (addresses re-derived from the lane id per call, opaque to the optimiser: kept live across the step loop they
+        //  are spilled, and a scratch reload in front of the loop costs an s_waitcnt vmcnt(0) INSIDE it -- the reload is
+        //  the youngest vector-memory operation, so waiting for it drains the whole weight prefetch every trip)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t zb = (uint32_t)(uintptr_t)zf + (uint32_t)(ln << 4);
+        uint32_t bp0 = zb + (uint32_t)kk0 * 1024;                               // tiles 0-3 / 4-7 of group kk0 + i
         uint32_t bp1 = bp0 + 4 * TILE_B;
 #pragma unroll
         for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<lds_frag_t>((uintptr_t)(bp0 + n * TILE_B));
-        uint32_t rp = zbase + (uint32_t)(wave * TILE_B) + (uint32_t)kk0 * 1024;   // own tile, this half / other half
-        uint32_t xp = zbase + (uint32_t)(wave * TILE_B) + (uint32_t)(kk0 ^ 8) * 1024;
+        uint32_t rp = zb + (uint32_t)(wave * TILE_B) + (uint32_t)kk0 * 1024;      // own tile, this half / other half
+        uint32_t xp = zb + (uint32_t)(wave * TILE_B) + (uint32_t)(kk0 ^ 8) * 1024;
         int sA = (w_frag0 + (kk0 + 2) * 4) * 1024;        // weight fragments two groups ahead
         int sR = (kk0 + 2) * 1024;                        // W_out fragments one trip ahead
         auto trip = [&](int i, auto tail_tag) {
@@ -283,7 +288,9 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
     };
     // [U ; F] group: abuf[0] holds group 16 on entry
     auto uf_group = [&](u32x4 ra_u) {
-        const uint32_t up = zbase + 16 * 1024;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t up = (uint32_t)(uintptr_t)zf + (uint32_t)(ln << 4) + 16 * 1024;
 #pragma unroll
         for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<lds_frag_t>((uintptr_t)(up + n * TILE_B));
         {   // yU_s = Wout[:, inputs] U_s (the feedback columns of that group carry zero weights)
