@@ -56,6 +56,10 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
     float2* tab_un = tab_in + NOWN * kin_p;
     char* in_slots = reinterpret_cast<char*>(tab_un + NOWN * 16);       // [NOWN][2][1 KB] raw float64 input rows
     int* tab_off = reinterpret_cast<int*>(in_slots + (size_t)NOWN * 2048);
+    // counter noise: the (frame, step) keys of the 128 frames, written once per step by the tile's own wave (sixteen
+    // lanes, one mix32) instead of being re-derived by every lane of every wave for each of its eight tiles; two
+    // buffers by step parity (set B reads step s while set A already writes step s + 1)
+    uint32_t* tab_ks = reinterpret_cast<uint32_t*>(tab_off + BT);
     for (int i = tid; i < BT; i += NTHREADS) {
         int gtmp;
         const int fr = slot_frame(p, slot0 + i, gtmp);
@@ -318,13 +322,12 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
     auto activate = [&](int s, auto n0_tag, auto n1_tag, int ln) {
         constexpr int N0 = decltype(n0_tag)::value, N1 = decltype(n1_tag)::value;
         const int g4 = ln >> 4, col = ln & 15;
-        const uint32_t step_mix = seed_hi ^ ((uint32_t)s * 0x85EBCA6BU + 0x27d4eb2fU);
         uint32_t k1[N1 - N0];
         int frs[N1 - N0];
 #pragma unroll
         for (int n = N0; n < N1; ++n) {
             const int t = n;
-            if (NOISE == ESN_NOISE_COUNTER) k1[n - N0] = tab_key[t * 16 + col];
+            if (NOISE == ESN_NOISE_COUNTER) k1[n - N0] = tab_ks[(s & 1) * BT + t * 16 + col];
             if (NOISE == ESN_NOISE_TENSOR) frs[n - N0] = tab_fr[t * 16 + col];
         }
 #pragma unroll
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
             uint32_t key = 0;
             const double* nz = nullptr;
             if (NOISE == ESN_NOISE_COUNTER)        // noise_key(seed, frame, step) + row4 stride: row4 = 16 wave + 4 m + g4
-                key = mix32(k1[n - N0] ^ step_mix) + (uint32_t)(16 * wave + g4) * 0x9E3779B9U;
+                key = k1[n - N0] + (uint32_t)(16 * wave + g4) * 0x9E3779B9U;
             if (NOISE == ESN_NOISE_TENSOR && frs[n - N0] >= 0)
                 nz = p.noise_u + ((size_t)frs[n - N0] * p.S + s) * n_res;
             char* dst = zf + (size_t)t * TILE_B + (size_t)(2 * wave) * 1024 + (size_t)ln * 16;
@@ -459,26 +462,42 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
         }
     };
 
+#ifdef ESN_STAMPS
+    unsigned long long sk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ESN_SK_ADD(i, a, b) sk_acc[i] += (b) - (a);
+#else
+#define ESN_SK_ADD(i, a, b)
+#endif
+    const uint32_t key1_own = tab_key[wave * 16 + (lane & 15)];
     next_step_A();
     ro_prefetch(0, false);
     if (lag) __syncthreads();                                      // slot 0: set A alone
     for (int s = 0; s < p.S; ++s) {
         const bool ro = has_ro && s > 0;
+        ESN_STAMP(t0)
         zero_acc();
         // ---- P0 (set A: slot 3s; set B: slot 3s+1 with the read-out of Y_s).  ONE code path for both sets: a
         // branch around the MFMAs makes the compiler shuffle the accumulators between its arms (hundreds of spills);
         // where a wave does not read out, its W_out fragments are zero (no traffic) and the MFMAs add nothing
         if (lag) __builtin_amdgcn_s_setprio(1);
+        if (NOISE == ESN_NOISE_COUNTER) {      // keys of step s for the own tile's frames: read from slot 3s+2 on
+            const uint32_t k = mix32(key1_own ^ seed_hi ^ ((uint32_t)s * 0x85EBCA6BU + 0x27d4eb2fU));
+            if (lane < 16) tab_ks[(s & 1) * BT + wave * 16 + lane] = k;
+        }
         if (lag && s > 0) commit_inputs_b(s);
         gemm_half(0, std::true_type{}, ro && lag);
         if (lag) { if (ro) finish_readout(s - 1 - p.transient, true); }
         if (lag) __builtin_amdgcn_s_setprio(0);
         ro_prefetch(NKH, ro && !lag);                              // set A: for P1, in flight over the barrier
+        ESN_STAMP(t1)
         __syncthreads();
+        ESN_STAMP(t2)
         // ---- P1 (set A: slot 3s+1 with the read-out; set B: slot 3s+2)
         gemm_half(NKH, std::true_type{}, ro && !lag);
         if (!lag) { if (ro) finish_readout(s - 1 - p.transient, true); }
+        ESN_STAMP(t3)
         __syncthreads();
+        ESN_STAMP(t4)
         // ---- P2: [U ; F] group + phase E
         __builtin_amdgcn_s_setprio(2);
         const u32x4 ra_u = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -486,14 +505,33 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
         int ln_e = lane;
         asm volatile("" : "+v"(ln_e));
         uf_group(ra_u);
+        ESN_STAMP(u1)
         activate(s, n_lo, n_mid, ln_e);
+        ESN_STAMP(u2)
         next_step_A();
         ro_prefetch(0, lag && has_ro && s + 1 < p.S);              // set B: for P0(s+1)
+        ESN_STAMP(u3)
         if (lag && s + 1 < p.S) dma_inputs_b(s + 1);               // last LDS read of the phase is behind us
+        ESN_STAMP(u4)
         activate(s, n_mid, n_hi, ln_e);
+        ESN_STAMP(u5)
         __builtin_amdgcn_s_setprio(0);
+        ESN_STAMP(t5)
         __syncthreads();
+        ESN_STAMP(t6)
+        ESN_SK_ADD(0, t0, t1) ESN_SK_ADD(1, t1, t2) ESN_SK_ADD(2, t2, t3)
+        ESN_SK_ADD(3, t3, t4) ESN_SK_ADD(4, t4, t5) ESN_SK_ADD(5, t5, t6)
+        ESN_SK_ADD(6, t4, u1) ESN_SK_ADD(7, u1, u2) ESN_SK_ADD(8, u2, u3) ESN_SK_ADD(9, u3, u4)
+        ESN_SK_ADD(10, u4, u5) ESN_SK_ADD(11, u5, t5)
     }
+#undef ESN_SK_ADD
+#ifdef ESN_STAMPS
+    if (p.stamps && blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 6; ++i) p.stamps[wave * 8 + i] = sk_acc[i];
+        for (int i = 0; i < 6; ++i) p.stamps[(8 + wave) * 8 + i] = sk_acc[6 + i];    // inside P2
+        p.stamps[wave * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);   // HW_ID
+    }
+#endif
     if (!lag) __syncthreads();                                     // slot 3S: set B finishes X_B(S)
     if (has_ro) {                                                  // Y_S = yU_{S-1} + Wout_x X_S
         for (int kk = 0; kk < 2 * NKH; ++kk) {
@@ -508,7 +546,7 @@ __global__ __launch_bounds__(512) void recur_skew16_kernel(RecurParams p) {
 template <typename TR>
 static int launch_skew16(const RecurParams& p, hipStream_t stream) {
     const int kin_p = p.g.kfb - p.g.kin;
-    const size_t lds = (size_t)8 * S16_NKK * 1024 + 4 * 128 + 4 * 128 + 8 * (size_t)8 * (kin_p + 16) + 8 * 2048 + 4 * 128;
+    const size_t lds = (size_t)8 * S16_NKK * 1024 + 4 * 128 + 4 * 128 + 8 * (size_t)8 * (kin_p + 16) + 8 * 2048 + 4 * 128 + 8 * 128;
     auto go = [&](auto kern) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

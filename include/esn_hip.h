@@ -51,8 +51,9 @@ enum esn_precision {
     ESN_F64 = 0,   /* float64, the reference's arithmetic: v_mfma_f64_16x16x4_f64 for batches (N_res <= 1024),
                       float64 FMA on the vector ALU for a single sequence and larger reservoirs */
     ESN_F32 = 1,   /* v_mfma_f32_32x32x2_f32: exact float32 products + accumulate */
-    ESN_F16 = 2,   /* v_mfma_f32_32x32x16_f16: fp16 operands, float32 accumulate  */
-    ESN_BF16 = 3   /* v_mfma_f32_32x32x16_bf16: bf16 operands, float32 accumulate */
+    ESN_F16 = 2,   /* v_mfma_f32_16x16x32_f16 (predict at 257..512 units) / v_mfma_f32_32x32x16_f16: fp16 operands,
+                      float32 accumulate */
+    ESN_BF16 = 3   /* the same with bf16 operands */
 };
 
 /* State-noise source (pyESN.py:124-125: + noise * (U[0,1) - 0.5)). */
@@ -87,6 +88,8 @@ int esn_abi_version(void);
  *   "rs"            "1" = fp16/bf16 predict at N_res 257..512 on the register-resident-state kernel
  *                   (esn_recur_rs.hip; an experiment kept for A/B runs, compiled only into ESN_WITH_RS=1 builds:
  *                   the product library answers -3) instead of the skewed LDS-state kernel
+ *   "s16"           "0" = fp16/bf16 predict at 257..512 units on the 32x32x16 skewed kernel instead of the 16x16x32 one
+ *                   (esn_recur_skew16_impl.h, the default: same schedule, 4 % less wall time at a higher clock; A/B runs)
  *   "big_gemm"      "0" = N_res > 1024 predict on the persistent kernel even when a workspace is given
  *   "cluster"       "0" = a single float64 sequence on the vector-ALU kernel even when a workspace is given
  *   "big_pipe"      "0" = N_res > 1024 predict with the round-2 main loop (two buffers, two barriers per chunk)
