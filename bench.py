@@ -297,6 +297,15 @@ def run_sweep(torch, params, *, precision, fit_precision, n_res, F, solve, reser
                 includes="frame generator + train + predict + detect + host syncs + counter read-back")
 
 
+def predict_kernel_name(precision, n_res):
+    """Name of the kernel the roofline record is about (csrc/esn_api.hip picks it from precision and shape)."""
+    if precision == "f64":
+        return "esn::recur_f64_mfma_kernel (predict)"
+    if precision in ("f16", "bf16") and 256 < n_res <= 512 and os.environ.get("ESN_S16") != "0":
+        return "esn::recur_skew16_kernel (predict, v_mfma_f32_16x16x32)"
+    return "esn::recur_mfma_kernel (predict)"
+
+
 def pmc_traffic(precision, G, F):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC pass taken on THIS
     workload (tools/pmc_traffic.py on the GPU box: FETCH_SIZE and WRITE_SIZE in separate passes,
@@ -439,8 +448,7 @@ def main():
             "fit_groups_flagged": head["fit_groups_flagged"],
             "predict_kernel_ms": head["predict_kernel_ms"],
             "predict_only_symbols_per_s": head["predict_only_symbols_per_s"],
-            "roofline": {"bound": "mfma", "kernel": "esn::recur_mfma_kernel (predict)" if args.precision != "f64"
-                         else "esn::recur_f64 (predict)",
+            "roofline": {"bound": "mfma", "kernel": predict_kernel_name(args.precision, args.n_res),
                          "achieved": head["achieved_tflops"],
                          "peak": head["peak"], "unit": "TFLOP/s", "frac": head["frac"], "traffic": traffic,
                          "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",

@@ -27,6 +27,8 @@ _TPL = re.compile(r"recur_mfma_kernel<([^>]*)>")
 def recur_kind(name):
     """'predict' / 'harvest' for an instantiation of recur_mfma_kernel<TR, NW, MT, NT, HARVEST, NOISE, SKEW>
     (the HARVEST template argument is the FIFTH one), else None."""
+    if "recur_skew16_kernel" in name:          # fp16/bf16 predict at 257..512 units on 16x16x32 MFMAs: predict only
+        return "predict"
     m = _TPL.search(name)
     if not m:
         return None
@@ -39,7 +41,7 @@ def recur_kind(name):
 def kernel_class(name):
     k = recur_kind(name)
     if k:
-        return "recur_mfma_" + k
+        return ("recur_skew16_" if "recur_skew16_kernel" in name else "recur_mfma_") + k
     for tag in ("recur_rs", "bigh_step", "big_step", "big_prep", "recur_cluster", "readout_chol_big", "recur_f64_mfma", "recur_f64", "readout_chol", "readout_qr", "detect_count", "pack_readout", "pack_weights",
                 "gen_frames", "gen_taps"):
         if tag in name:

@@ -34,8 +34,9 @@ def main():
     bench_args = ["--precision", a.precision, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra",
                   "--blocks", a.blocks]
     out = {"precision": a.precision, "blocks": int(a.blocks), "frames_per_block": 75,
-           "kernel": "esn::recur_mfma_kernel (predict)",
-           "kernel_match": "template argument HARVEST == false of recur_mfma_kernel<...>"}
+           "kernel": "esn::recur_skew16_kernel / esn::recur_mfma_kernel (predict)",
+           "kernel_match": "recur_skew16_kernel<...> (predict only) or template argument HARVEST == false of "
+                           "recur_mfma_kernel<...>"}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(ROOT, "gpurun_out", f"pmc_{counter.lower()}_{a.precision}")
         shutil.rmtree(d, ignore_errors=True)
