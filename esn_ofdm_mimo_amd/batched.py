@@ -153,7 +153,18 @@ class ReservoirBank:
                      ptr(E), ptr(ws), wbytes, _lib.stream_handle()), "esn_harvest_batch")
             if wbytes and precision == "f64" and g == 1:
                 self._cluster_err = ws[wbytes - 64:wbytes - 60]      # error word of the single-sequence cluster kernel
+            # fp16/bf16 at 257..512 units: clusters of eight workgroups with the matrix resident in LDS
+            # (csrc/esn_harvest_cluster.hip); their bounded waits raise the same kind of error word
+            self.harvest_timeout = (ws[wbytes - 64:wbytes - 60].view(torch.int32)
+                                    if wbytes and precision in ("f16", "bf16") and self.n_reservoir <= 512 else None)
         return E
+
+    def raise_if_harvest_timed_out(self):
+        """Host-synchronising check of the last fp16/bf16 harvest on the cluster kernel (see harvest)."""
+        w = getattr(self, "harvest_timeout", None)
+        if w is not None and int(w.item()) != 0:
+            raise _lib.EsnHipError("harvest cluster kernel: a workgroup timed out waiting for the others "
+                                   "(the device is oversubscribed); the extended states are invalid")
 
     def chol_fits(self, rows, cols):
         """Shapes the Cholesky solve covers (esn_readout_solve_chol_batch): Gram dimension up to 128 in LDS,

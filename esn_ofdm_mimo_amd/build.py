@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libesn_hip.so")
 SOURCES = ["esn_api.hip", "esn_host.hip", "esn_pack.hip", "esn_recur_f64.hip", "esn_recur_f64_mfma.hip", "esn_recur_mfma.hip",
-           "esn_recur_big.hip", "esn_recur_cluster.hip", "esn_recur_mfma_f32.hip", "esn_recur_mfma_f16.hip", "esn_recur_mfma_bf16.hip", "esn_recur_skew16.hip",
+           "esn_recur_big.hip", "esn_recur_cluster.hip", "esn_recur_mfma_f32.hip", "esn_recur_mfma_f16.hip", "esn_recur_mfma_bf16.hip", "esn_recur_skew16.hip", "esn_harvest_cluster.hip",
            "esn_solve.hip", "esn_detect.hip", "esn_gen.hip", "esn_baseline.hip", "esn_coded.hip"]
 # the register-resident-state predict kernel is a kept negative result: it is compiled only into
 # experiment builds (`ESN_WITH_RS=1 python esn_ofdm_mimo_amd/build.py --variant rs`), never into the product library

@@ -35,6 +35,10 @@ int launch_recur_cluster(const RecurParams& p, void* workspace, hipStream_t stre
 // esn_recur_mfma.hip
 bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, Geometry* g);
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
+// esn_harvest_cluster.hip
+bool harvest_cluster_applies(int precision, const RecurParams& p);
+size_t harvest_cluster_workspace_bytes(int n_pilots);
+int launch_harvest_cluster(int precision, const RecurParams& p, void* workspace, hipStream_t stream);
 // esn_recur_skew16.hip
 int launch_recur_skew16(int precision, const RecurParams& p, hipStream_t stream);
 // esn_pack.hip
@@ -107,6 +111,8 @@ Knobs& knobs() {
         x.harvest_gemm = (v && v[0] == '1') ? 1 : 0;
         v = getenv("ESN_BIG_NT");
         x.big_nt = (v && v[0] == '4') ? 4 : 2;
+        v = getenv("ESN_HCLUSTER");
+        x.hcluster = (v && v[0] == '0') ? 0 : 1;
         v = getenv("ESN_S16");
         x.s16 = (v && v[0] == '0') ? 0 : 1;
         v = getenv("ESN_BIG_PIPE");
@@ -201,6 +207,7 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "gen_ko")) { k.gen_ko = value ? atoi(value) : 0; return 0; }
     if (!strcmp(key, "harvest_gemm")) { k.harvest_gemm = (value && value[0] == '1') ? 1 : 0; return 0; }
     if (!strcmp(key, "big_nt")) { k.big_nt = (value && value[0] == '4') ? 4 : 2; return 0; }
+    if (!strcmp(key, "hcluster")) { k.hcluster = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "s16")) { k.s16 = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "big_pipe")) { k.big_pipe = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
@@ -389,8 +396,9 @@ size_t esn_harvest_workspace_bytes(int precision, const esn_shape_t* shape, int 
     RecurParams p;
     if (n_groups <= 0) return 0;
     if (fill_common(p, precision, shape, "esn_harvest_workspace_bytes", true)) return 0;
-    p.harvest = 1; p.n_groups = n_groups; p.n_frames = n_groups;
+    p.harvest = 1; p.n_groups = n_groups; p.n_frames = n_groups; p.F = 1;
     if (knobs().cluster && cluster_applies(precision, p)) return cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, true);
+    if (knobs().hcluster && harvest_cluster_applies(precision, p)) return harvest_cluster_workspace_bytes(n_groups);
     if (!big_harvest_applies(precision, p)) return 0;
     return big_harvest_workspace_bytes(n_groups, p.g.Kp);
 }
@@ -441,6 +449,14 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
             return fail(-1, "esn_harvest_batch: workspace holds %zu bytes, esn_harvest_workspace_bytes says %zu",
                         workspace_bytes, need);
         return hip_fail(launch_recur_cluster(p, workspace, (hipStream_t)stream), "esn_harvest_batch");
+    }
+    // 257..512 units, fp16/bf16, shared reservoir: clusters of eight workgroups with the matrix resident in LDS
+    if (workspace && knobs().hcluster && harvest_cluster_applies(precision, p)) {
+        const size_t need = harvest_cluster_workspace_bytes(n_groups);
+        if (workspace_bytes < need)
+            return fail(-1, "esn_harvest_batch: workspace holds %zu bytes, esn_harvest_workspace_bytes says %zu",
+                        workspace_bytes, need);
+        return hip_fail(launch_harvest_cluster(precision, p, workspace, (hipStream_t)stream), "esn_harvest_batch");
     }
     // large reservoirs: one GEMM launch per step when the caller lends a workspace (else the persistent kernel)
     if (workspace && knobs().big_gemm && big_harvest_applies(precision, p)) {

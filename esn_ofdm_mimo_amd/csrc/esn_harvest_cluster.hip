@@ -1,0 +1,325 @@
+// Batched state harvest of ESN.fit (pyESN.py:176-182) at 257..512 reservoir units, fp16 / bf16, with the reservoir
+// matrix RESIDENT IN LDS.
+//
+// A fit has ONE training sequence per trained ESN (2048 pilots at the benchmark size where predict has 153 600
+// frames).  The persistent harvest kernel (esn_recur_mfma_impl.h, HARVEST) gives a tile of 32 pilots to one workgroup,
+// which re-streams the whole 557 KB weight image from L2 every timestep: 64 workgroups on 256 CUs, each bound by its
+// CU's L2 port (19 k cycles per step, 5 % of the MFMA peak); more, smaller tiles only multiply the aggregate stream
+// (DESIGN 3.1).  Here a CLUSTER of eight co-resident workgroups owns 64 pilots for all T - 1 steps: workgroup c keeps
+// rows [64 c, 64 c + 64) of Wext = [W | W_in | W_feedb] in its LDS (69.6 KB: slice c of the 16x16x32 weight image of
+// esn_pack_weights, as it is) next to the fragment-major state image of its 64 pilots (69.6 KB, the layout of
+// esn_recur_skew16_impl.h), and per step
+//     multiplies  its 64 rows x 64 pilots x 544 k on v_mfma_f32_16x16x32 (4 waves of 2 x 2 tiles, 68 MFMAs each),
+//     activates   (tanh + state noise -> operand type), stores its rows of E[:, s + 1],
+//     publishes   its 8 KB slice of X_{s+1} and gathers the seven others' -- nothing else moves: no weight traffic.
+// The hand-off is the data-tagged granule form of esn_recur_cluster.hip: an 8-byte granule carries four state values
+// AND the step tag, in the one bit of every half that |x| < 2 leaves free (bit 14: tanh + noise never reaches 2), is
+// written by one agent-scope store and polled by agent-scope loads until the tag reads the awaited step; two
+// buffers by step parity; every spin is bounded (a timed-out workgroup raises the error word in the last 64 bytes of
+// the workspace and leaves, and so does everybody else).  Clusters are laid out so that their eight workgroups
+// share an XCD (block id mod 8), i.e. one L2.
+// Arithmetic, noise stream (counter noise keyed by (seed, global pilot, step, row)) and the rounding of the states to
+// the operand type are those of the persistent harvest kernel; only the summation order inside a dot product differs.
+#include "esn_recur_mfma_impl.h"
+
+namespace esn {
+
+constexpr int HC_C = 8;                           // workgroups per cluster = row slices of 64
+constexpr int HC_P = 64;                          // pilots per cluster = 4 column tiles of 16
+constexpr int HC_NT = 256;                        // 4 waves: (row-tile pair vr) x (pilot-tile pair vc)
+constexpr int HC_NKK = 17;
+constexpr int HC_SLICE = HC_NKK * 4 * 1024;       // bytes of a workgroup's weight slice and of its state image
+constexpr int HC_NG = 14;                         // 16-byte chunks a thread gathers per step: 7 x 8 x 64 / 256
+constexpr uint32_t HC_SPIN_LIMIT = 1u << 22;
+constexpr unsigned long long HC_TAGMASK = 0x4000400040004000ULL;
+
+static inline int hc_clusters(int n_pilots) { return (n_pilots + HC_P - 1) / HC_P; }
+size_t harvest_cluster_workspace_bytes(int n_pilots) {
+    return (size_t)hc_clusters(n_pilots) * 2 * HC_C * 8 * 1024 + 64;         // two parities x 8 members x 8 KB, + error word
+}
+
+__device__ __forceinline__ unsigned long long hc_tag_bits(int tag) {         // tag 1..15 -> bit 14 of each of four halves
+    return ((unsigned long long)(tag & 1) << 14) | ((unsigned long long)((tag >> 1) & 1) << 30) |
+           ((unsigned long long)((tag >> 2) & 1) << 46) | ((unsigned long long)((tag >> 3) & 1) << 62);
+}
+
+template <typename TR, int NOISE>
+__global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, int n_clusters, unsigned long long* xch) {
+    extern __shared__ __attribute__((aligned(16))) char hsm[];
+    char* Wl = hsm;                                // [kk][m][lane][16 B]: slice c of the 16x16x32 weight image
+    char* Zf = hsm + HC_SLICE;                     // [tile][kk][lane][16 B]
+    int* tab_fr = reinterpret_cast<int*>(Zf + HC_SLICE);                   // [64] pilot (= frame) index or -1
+    __shared__ int sh_dead;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vr = wave >> 1, vc = wave & 1;
+    const int g4 = lane >> 4, col = lane & 15;
+    const int lane16 = lane * 16;
+    const Geometry& g = p.g;
+    const int n_res = p.n_res, n_in = p.n_in, n_out = p.n_out;
+    const int kin_p = g.kfb - g.kin;
+    const int ncols = n_res + n_in;
+    // block -> (cluster, member): the eight members of a cluster are consecutive blocks of ONE XCD (block id mod 8)
+    const int cpx = (n_clusters + 7) / 8;                                   // clusters per XCD
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int cluster = xcd * cpx + (li >> 3), c = li & 7;
+    if (cluster >= n_clusters) return;                                      // (a whole cluster leaves together)
+    unsigned int* err = reinterpret_cast<unsigned int*>(xch + (size_t)n_clusters * 2 * HC_C * 1024);
+    unsigned long long* xc = xch + (size_t)cluster * 2 * HC_C * 1024;        // [parity][member][block][lane][2]
+    if (tid == 0) sh_dead = 0;
+
+    // ---- resident operands --------------------------------------------------------------------------------
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.packed_w) + p.w16_off
+                                                          + (size_t)c * HC_SLICE);
+        for (int i = tid; i < HC_SLICE / 16; i += HC_NT) reinterpret_cast<u32x4*>(Wl)[i] = src[i];
+        for (int i = tid; i < HC_SLICE / 16; i += HC_NT) reinterpret_cast<u32x4*>(Zf)[i] = u32x4{0, 0, 0, 0};   // X_0 = 0
+    }
+    const int pil0 = cluster * HC_P;
+    if (tid < HC_P) tab_fr[tid] = (pil0 + tid < p.n_groups) ? pil0 + tid : -1;
+    auto store_E4 = [&](size_t idx, float v0, float v1, float v2, float v3) {      // idx multiple of 4
+        if (p.E32) {
+            *reinterpret_cast<f32x4*>(p.E32 + idx) = f32x4{v0, v1, v2, v3};
+        } else {
+            typedef double f64x2s __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f64x2s*>(p.E + idx) = f64x2s{(double)v0, (double)v1};
+            *reinterpret_cast<f64x2s*>(p.E + idx + 2) = f64x2s{(double)v2, (double)v3};
+        }
+    };
+    // ---- [U ; F] staging: thread (pilot f = tid & 63, chunk q = tid >> 6) builds the eight positions 8 q .. 8 q + 7
+    // of the [U ; F] group of its pilot: inputs row s + 1 scaled (pyESN.py:180-182), teacher row s scaled
+    const int sf = tid & 63, sq = tid >> 6;
+    const int s_pil = pil0 + sf;
+    const bool s_ok = s_pil < p.n_groups;
+    double uf_sc[8], uf_sh[8];
+    int uf_kind[8];                                                          // 0 = zero, 1 = input, 2 = teacher
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int pos = 8 * sq + e;
+        uf_kind[e] = 0; uf_sc[e] = 0.0; uf_sh[e] = 0.0;
+        if (!s_ok) continue;
+        if (pos < n_in) {
+            uf_kind[e] = 1;
+            uf_sc[e] = p.in_scale ? p.in_scale[(size_t)s_pil * n_in + pos] : 1.0;
+            uf_sh[e] = p.in_shift ? p.in_shift[(size_t)s_pil * n_in + pos] : 0.0;
+        } else if (pos >= kin_p && pos < kin_p + n_out) {
+            uf_kind[e] = 2;
+            uf_sc[e] = p.t_scale ? p.t_scale[(size_t)s_pil * n_out + (pos - kin_p)] : 1.0;
+            uf_sh[e] = p.t_shift ? p.t_shift[(size_t)s_pil * n_out + (pos - kin_p)] : 0.0;
+        }
+    }
+    // raw operands of step s: input row s + 1, teacher row s
+    auto fetch_uf = [&](int s, double (&raw)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pos = 8 * sq + e;
+            raw[e] = 0.0;
+            if (s >= p.S) continue;
+            if (uf_kind[e] == 1) raw[e] = p.U[((size_t)s_pil * p.T_in + (s + 1)) * n_in + pos];
+            else if (uf_kind[e] == 2) raw[e] = p.D[((size_t)s_pil * (p.S + 1) + s) * n_out + (pos - kin_p)];
+        }
+    };
+    // scaled values -> the [U ; F] group of the pilot's tile; member 0 also writes the input columns of E row s + 1
+    auto stage_uf = [&](int s, const double (&raw)[8]) {
+        uint32_t out[4];
+        double sv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sv[e] = uf_kind[e] ? raw[e] * uf_sc[e] + uf_sh[e] : 0.0;      // as the persistent kernel
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = TR::pack2((float)sv[2 * e], (float)sv[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(Zf + ((size_t)((sf >> 4) * HC_NKK + 16) * 64 + sq * 16 + (sf & 15)) * 16) =
+            u32x4{out[0], out[1], out[2], out[3]};
+        if (c == 0 && s_ok && 8 * sq < n_in) {
+            const size_t e0 = ((size_t)s_pil * (p.S + 1) + (s + 1)) * ncols + n_res + 8 * sq;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (8 * sq + e < n_in) { if (p.E32) p.E32[e0 + e] = (float)sv[e]; else p.E[e0 + e] = sv[e]; }
+        }
+    };
+    if (c == 0 && s_ok && sq == 0) {                                         // E row 0 = [0, scale(u[0])]  (pyESN.py:179,189)
+        const size_t e0 = (size_t)s_pil * (p.S + 1) * ncols;
+        for (int k = 0; k < ncols; ++k) {
+            double v = 0.0;
+            if (k >= n_res) {
+                const int ci = k - n_res;
+                const double sc = p.in_scale ? p.in_scale[(size_t)s_pil * n_in + ci] : 1.0;
+                const double sh = p.in_shift ? p.in_shift[(size_t)s_pil * n_in + ci] : 0.0;
+                v = p.U[(size_t)s_pil * p.T_in * n_in + ci] * sc + sh;
+            }
+            if (p.E32) p.E32[e0 + k] = (float)v; else p.E[e0 + k] = v;
+        }
+    }
+    __syncthreads();
+    double raw_cur[8], raw_nx[8];
+    fetch_uf(0, raw_cur);
+    stage_uf(0, raw_cur);
+    fetch_uf(1, raw_cur);
+
+    const float noise = (float)p.noise;
+    const float n_c1 = noise * (1.0f / 256.0f), n_c0 = noise * (0.5f / 256.0f - 0.5f);
+    // the two pilots of this lane (tiles 2 vc, 2 vc + 1, column col): frame index and step-independent key half
+    int fr2[2];
+    uint32_t key1[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int pl = pil0 + (2 * vc + n) * 16 + col;
+        fr2[n] = pl < p.n_groups ? pl : -1;
+        key1[n] = mix32((uint32_t)p.seed ^ (((uint32_t)pl + p.frame_off) * 0x9E3779B9U));
+    }
+    const uint32_t seed_hi = (uint32_t)(p.seed >> 32);
+    __syncthreads();
+
+    // gather the seven other members' slices of X_{s+1} (tag of step s) into the state image; false on time-out
+    auto gather = [&](int s) -> bool {
+        const int par = s & 1;
+        const unsigned long long want = hc_tag_bits(s % 15 + 1);
+        unsigned pending = (1u << HC_NG) - 1;
+        uint32_t spins = 0;
+        bool ok = true;
+        while (pending) {
+            unsigned long long lo[HC_NG], hi[HC_NG];
+#pragma unroll
+            for (int j = 0; j < HC_NG; ++j)
+                if (pending & (1u << j)) {
+                    const int ch = tid + j * HC_NT;                          // chunk: peer (ch >> 9), block, lane
+                    const int cp = (c + 1 + (ch >> 9)) & 7;
+                    const unsigned long long* src = xc + ((size_t)(par * HC_C + cp) * 8 + ((ch >> 6) & 7)) * 128 + (ch & 63) * 2;
+                    lo[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[j] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+            for (int j = 0; j < HC_NG; ++j)
+                if ((pending & (1u << j)) && (lo[j] & HC_TAGMASK) == want && (hi[j] & HC_TAGMASK) == want) {
+                    const int ch = tid + j * HC_NT;
+                    const int cp = (c + 1 + (ch >> 9)) & 7, blk = (ch >> 6) & 7, ln = ch & 63;
+                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u64x2*>(Zf + ((size_t)((blk >> 1) * HC_NKK + 2 * cp + (blk & 1)) * 64 + ln) * 16) =
+                        u64x2{lo[j] & ~HC_TAGMASK, hi[j] & ~HC_TAGMASK};
+                    pending &= ~(1u << j);
+                }
+            if (pending) {
+                if (++spins > HC_SPIN_LIMIT ||
+                    ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (!ok) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_dead = 1;
+        }
+        __syncthreads();
+        return sh_dead == 0;
+    };
+
+    const char* wl_w = Wl + (size_t)(2 * vr) * 1024 + lane16;                // fragments (kk, 2 vr), (kk, 2 vr + 1)
+    const char* zf_w = Zf + (size_t)(2 * vc) * HC_NKK * 1024 + lane16;        // tiles 2 vc, 2 vc + 1
+    for (int s = 0; s < p.S; ++s) {
+        fetch_uf(s + 2, raw_nx);                                             // two steps ahead of its use (see stage_uf below)
+        // ---- P[64 x 64] = Wext[rows of c] * [X_s ; U ; F]: wave (vr, vc) takes 2 row tiles x 2 pilot tiles ----
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < HC_NKK; ++kk) {
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(wl_w + (size_t)kk * 4096);
+            const u32x4 a1 = *reinterpret_cast<const u32x4*>(wl_w + (size_t)kk * 4096 + 1024);
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(zf_w + (size_t)kk * 1024);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(HC_NKK + kk) * 1024);
+            TR::mma16(acc[0][0], a0, b0);
+            TR::mma16(acc[1][0], a1, b0);
+            TR::mma16(acc[0][1], a0, b1);
+            TR::mma16(acc[1][1], a1, b1);
+        }
+        __syncthreads();                                                     // every wave has read the image of step s
+        // ---- activation + noise -> operand type; own slice into the image, to the peers, and into E row s + 1 ----
+        const uint32_t step_mix = seed_hi ^ ((uint32_t)s * 0x85EBCA6BU + 0x27d4eb2fU);
+        const unsigned long long tagb = hc_tag_bits(s % 15 + 1);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int t = 2 * vc + n;
+            uint32_t key = 0;
+            const double* nz = nullptr;
+            if (NOISE == ESN_NOISE_COUNTER) key = mix32(key1[n] ^ step_mix) + (uint32_t)(16 * c + 8 * vr + g4) * 0x9E3779B9U;
+            if (NOISE == ESN_NOISE_TENSOR && fr2[n] >= 0) nz = p.noise_u + ((size_t)fr2[n] * p.S + s) * n_res;
+            uint32_t out[4];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int row = 64 * c + 32 * vr + 16 * tt + 4 * g4;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[tt][n][j]);
+                if (NOISE == ESN_NOISE_COUNTER) {
+                    const uint32_t sq4 = noise_mix(key + (uint32_t)(4 * tt) * 0x9E3779B9U);
+                    v[0] = fmaf((float)(sq4 & 0xffU), n_c1, v[0] + n_c0);
+                    v[1] = fmaf((float)((sq4 >> 8) & 0xffU), n_c1, v[1] + n_c0);
+                    v[2] = fmaf((float)((sq4 >> 16) & 0xffU), n_c1, v[2] + n_c0);
+                    v[3] = fmaf((float)(sq4 >> 24), n_c1, v[3] + n_c0);
+                } else if (NOISE == ESN_NOISE_TENSOR) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+                }
+                out[2 * tt] = TR::pack2(v[0], v[1]);
+                out[2 * tt + 1] = TR::pack2(v[2], v[3]);
+                if (fr2[n] >= 0 && row < n_res) {                            // E holds the ROUNDED state (what the recurrence continues from)
+                    float r[4];
+                    TR::unpack2(out[2 * tt], r[0], r[1]);
+                    TR::unpack2(out[2 * tt + 1], r[2], r[3]);
+                    store_E4(((size_t)fr2[n] * (p.S + 1) + (s + 1)) * ncols + row, r[0], r[1], r[2], r[3]);
+                }
+            }
+            *reinterpret_cast<u32x4*>(Zf + ((size_t)(t * HC_NKK + 2 * c + vr) * 64 + lane) * 16) = u32x4{out[0], out[1], out[2], out[3]};
+            if (s + 1 < p.S) {
+                unsigned long long* dst = xc + ((size_t)((s & 1) * HC_C + c) * 8 + (t * 2 + vr)) * 128 + lane * 2;
+                __hip_atomic_store(dst, ((unsigned long long)out[0] | ((unsigned long long)out[1] << 32)) | tagb,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, ((unsigned long long)out[2] | ((unsigned long long)out[3] << 32)) | tagb,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (s + 1 == p.S) break;                                             // (the last state is in E; nobody reads it back)
+        stage_uf(s + 1, raw_cur);                                            // [U ; F] of step s + 1 (fetched one step ago)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw_cur[e] = raw_nx[e];
+        if (!gather(s)) return;                                              // (ends with a workgroup barrier)
+    }
+}
+
+bool harvest_cluster_applies(int precision, const RecurParams& p) {
+    return (precision == ESN_F16 || precision == ESN_BF16) && p.harvest && p.g.s16 && p.n_wsets == 1 && p.F == 1 &&
+           p.n_groups >= 1 && (p.n_res % 4) == 0 && (p.n_res + p.n_in) % 4 == 0;
+}
+
+template <typename TR>
+static int launch_hc(const RecurParams& p, int n_clusters, unsigned long long* xch, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)HC_SLICE + 4 * HC_P;
+    const int grid = 64 * ((n_clusters + 7) / 8);
+    auto go = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(HC_NT), lds, stream, p, n_clusters, xch);
+        return (int)hipGetLastError();
+    };
+    switch (p.noise_mode) {
+        case ESN_NOISE_NONE: return go(harvest_cluster_kernel<TR, ESN_NOISE_NONE>);
+        case ESN_NOISE_TENSOR: return go(harvest_cluster_kernel<TR, ESN_NOISE_TENSOR>);
+        default: return go(harvest_cluster_kernel<TR, ESN_NOISE_COUNTER>);
+    }
+}
+
+int launch_harvest_cluster(int precision, const RecurParams& p, void* workspace, hipStream_t stream) {
+    const int n_clusters = hc_clusters(p.n_groups);
+    hipError_t e = hipMemsetAsync(workspace, 0, harvest_cluster_workspace_bytes(p.n_groups), stream);   // tags start at 1
+    if (e != hipSuccess) return (int)e;
+    unsigned long long* xch = reinterpret_cast<unsigned long long*>(workspace);
+    if (precision == ESN_F16) return launch_hc<TraitsF16>(p, n_clusters, xch, stream);
+    if (precision == ESN_BF16) return launch_hc<TraitsBF16>(p, n_clusters, xch, stream);
+    return -1;
+}
+
+}  // namespace esn

@@ -105,6 +105,11 @@ struct TraitsF16 {
         typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(uint32_t, h16x2v{(_Float16)v0, (_Float16)v1});
     }
+    static __device__ __forceinline__ void unpack2(uint32_t w, float& v0, float& v1) {
+        typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
+        const h16x2v h = __builtin_bit_cast(h16x2v, w);
+        v0 = (float)h[0]; v1 = (float)h[1];
+    }
     static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const _Float16*>(src); }
     static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 8-byte aligned
         const h16x4 t = *reinterpret_cast<const h16x4*>(src);
@@ -139,6 +144,9 @@ struct TraitsBF16 {
     static __device__ __forceinline__ uint32_t pack2(float v0, float v1) {
         typedef __bf16 b16x2v __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(uint32_t, b16x2v{(__bf16)v0, (__bf16)v1});
+    }
+    static __device__ __forceinline__ void unpack2(uint32_t w, float& v0, float& v1) {
+        v0 = __uint_as_float(w << 16); v1 = __uint_as_float(w & 0xffff0000u);
     }
     static __device__ __forceinline__ float load1(const char* src) { return (float)*reinterpret_cast<const __bf16*>(src); }
     static __device__ __forceinline__ void load4(const char* src, float (&v)[4]) {     // 8-byte aligned

@@ -389,6 +389,14 @@ class DetectorSweep:
         self.detect(data["data_y"], data["data_bits"], F, err, nb, seed=self.stream_seed(si, 1), group_offset=ids[0])
         flagged = self.bank.fit_status.ne(0).sum().to(torch.int64) if not repair else torch.zeros(
             (), dtype=torch.int64, device=self.device)
+        # (a timed-out harvest cluster counts as a flagged fit: the chunk is then redone with `repair`, whose host
+        #  read raises)
+        ht = getattr(self.bank, "harvest_timeout", None)
+        if ht is not None:
+            if repair:
+                self.bank.raise_if_harvest_timed_out()
+            else:
+                flagged = flagged + ht.ne(0).sum().to(torch.int64)
         return torch.stack([err.sum(), nb.sum(), flagged])
 
     def run(self, ebno_list, blocks_per_snr, frames_per_block=None, chunk_blocks=None, dist=None):
