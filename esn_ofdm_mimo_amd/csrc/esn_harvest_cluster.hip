@@ -46,8 +46,7 @@ __device__ __forceinline__ unsigned long long hc_tag_bits(int tag) {         // 
 template <typename TR, int NOISE>
 __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, int n_clusters, unsigned long long* xch) {
     extern __shared__ __attribute__((aligned(16))) char hsm[];
-    char* Wl = hsm;                                // [kk][m][lane][16 B]: slice c of the 16x16x32 weight image
-    char* Zf = hsm + HC_SLICE;                     // [tile][kk][lane][16 B]
+    char* Zf = hsm;                                // [tile][kk][lane][16 B]
     int* tab_fr = reinterpret_cast<int*>(Zf + HC_SLICE);                   // [64] pilot (= frame) index or -1
     __shared__ int sh_dead;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,11 +67,17 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     unsigned long long* xc = xch + (size_t)cluster * 2 * HC_C * 1024;        // [parity][member][block][lane][2]
     if (tid == 0) sh_dead = 0;
 
-    // ---- resident operands --------------------------------------------------------------------------------
+    // ---- resident operands: the wave's 2 row tiles x 17 groups of weight fragments live in REGISTERS for the whole
+    // launch (136 of the 512 a lone wave per SIMD may hold): slice c of the 16x16x32 image, fragment (kk, m) at
+    // ((c NKK + kk) 4 + m) KB.  Only the state image is in LDS.
+    u32x4 areg[HC_NKK][2];
     {
-        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.packed_w) + p.w16_off
-                                                          + (size_t)c * HC_SLICE);
-        for (int i = tid; i < HC_SLICE / 16; i += HC_NT) reinterpret_cast<u32x4*>(Wl)[i] = src[i];
+        const char* src = reinterpret_cast<const char*>(p.packed_w) + p.w16_off + (size_t)c * HC_SLICE + (size_t)(2 * vr) * 1024 + lane16;
+#pragma unroll
+        for (int kk = 0; kk < HC_NKK; ++kk) {
+            areg[kk][0] = *reinterpret_cast<const u32x4*>(src + (size_t)kk * 4096);
+            areg[kk][1] = *reinterpret_cast<const u32x4*>(src + (size_t)kk * 4096 + 1024);
+        }
         for (int i = tid; i < HC_SLICE / 16; i += HC_NT) reinterpret_cast<u32x4*>(Zf)[i] = u32x4{0, 0, 0, 0};   // X_0 = 0
     }
     const int pil0 = cluster * HC_P;
@@ -108,16 +113,21 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
             uf_sh[e] = p.t_shift ? p.t_shift[(size_t)s_pil * n_out + (pos - kin_p)] : 0.0;
         }
     }
-    // raw operands of step s: input row s + 1, teacher row s
-    auto fetch_uf = [&](int s, double (&raw)[8]) {
+    // raw operands of step s: input row s + 1, teacher row s.  Branch-free: every position has a base pointer and a
+    // per-step stride (positions that hold nothing point at a valid address with stride 0 and are masked when staged)
+    const double* uf_ptr[8];
+    int uf_stride[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int pos = 8 * sq + e;
-            raw[e] = 0.0;
-            if (s >= p.S) continue;
-            if (uf_kind[e] == 1) raw[e] = p.U[((size_t)s_pil * p.T_in + (s + 1)) * n_in + pos];
-            else if (uf_kind[e] == 2) raw[e] = p.D[((size_t)s_pil * (p.S + 1) + s) * n_out + (pos - kin_p)];
-        }
+    for (int e = 0; e < 8; ++e) {
+        const int pos = 8 * sq + e;
+        uf_ptr[e] = p.U; uf_stride[e] = 0;
+        if (uf_kind[e] == 1) { uf_ptr[e] = p.U + ((size_t)s_pil * p.T_in + 1) * n_in + pos; uf_stride[e] = n_in; }
+        if (uf_kind[e] == 2) { uf_ptr[e] = p.D + (size_t)s_pil * (p.S + 1) * n_out + (pos - kin_p); uf_stride[e] = n_out; }
+    }
+    auto fetch_uf = [&](int s, double (&raw)[8]) {
+        const int sc = s < p.S ? s : p.S - 1;                                // (past the end: any valid row, never staged)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[e] = uf_ptr[e][(size_t)sc * uf_stride[e]];
     };
     // scaled values -> the [U ; F] group of the pilot's tile; member 0 also writes the input columns of E row s + 1
     auto stage_uf = [&](int s, const double (&raw)[8]) {
@@ -169,23 +179,36 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     const uint32_t seed_hi = (uint32_t)(p.seed >> 32);
     __syncthreads();
 
+#ifdef ESN_STAMPS
+    unsigned long long hc_polls = 0;
+#endif
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(xc), 0, 2 * HC_C * 8192, 0x00020000);
     // gather the seven other members' slices of X_{s+1} (tag of step s) into the state image; false on time-out
     auto gather = [&](int s) -> bool {
         const int par = s & 1;
         const unsigned long long want = hc_tag_bits(s % 15 + 1);
         unsigned pending = (1u << HC_NG) - 1;
         uint32_t spins = 0;
+#ifdef ESN_STAMPS
+        hc_polls = 0;
+#endif
         bool ok = true;
         while (pending) {
             unsigned long long lo[HC_NG], hi[HC_NG];
+#ifdef ESN_STAMPS
+            ++hc_polls;
+#endif
+            // one 16-byte agent-scope (sc1) load per chunk: each 8-byte half carries its own tag, so a torn pair is
+            // simply not accepted yet
 #pragma unroll
             for (int j = 0; j < HC_NG; ++j)
                 if (pending & (1u << j)) {
                     const int ch = tid + j * HC_NT;                          // chunk: peer (ch >> 9), block, lane
                     const int cp = (c + 1 + (ch >> 9)) & 7;
-                    const unsigned long long* src = xc + ((size_t)(par * HC_C + cp) * 8 + ((ch >> 6) & 7)) * 128 + (ch & 63) * 2;
-                    lo[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hi[j] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int off = (((par * HC_C + cp) * 8 + ((ch >> 6) & 7)) * 64 + (ch & 63)) * 16;
+                    const u32x4 w = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 16));
+                    lo[j] = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+                    hi[j] = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
                 }
 #pragma unroll
             for (int j = 0; j < HC_NG; ++j)
@@ -214,9 +237,15 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
         return sh_dead == 0;
     };
 
-    const char* wl_w = Wl + (size_t)(2 * vr) * 1024 + lane16;                // fragments (kk, 2 vr), (kk, 2 vr + 1)
     const char* zf_w = Zf + (size_t)(2 * vc) * HC_NKK * 1024 + lane16;        // tiles 2 vc, 2 vc + 1
+#ifdef ESN_STAMPS
+    unsigned long long hst[4] = {0, 0, 0, 0};
+#define HC_T(v) const unsigned long long v = __builtin_amdgcn_s_memrealtime();
+#else
+#define HC_T(v)
+#endif
     for (int s = 0; s < p.S; ++s) {
+        HC_T(ht0)
         fetch_uf(s + 2, raw_nx);                                             // two steps ahead of its use (see stage_uf below)
         // ---- P[64 x 64] = Wext[rows of c] * [X_s ; U ; F]: wave (vr, vc) takes 2 row tiles x 2 pilot tiles ----
         f32x4 acc[2][2];
@@ -224,21 +253,39 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // state fragments four groups ahead in a ring of registers (left to itself the compiler reads one group at a
+        // time into the same registers and waits for it: 17 exposed LDS latencies per step)
+        {
+            u32x4 bq[4][2];
 #pragma unroll
-        for (int kk = 0; kk < HC_NKK; ++kk) {
-            const u32x4 a0 = *reinterpret_cast<const u32x4*>(wl_w + (size_t)kk * 4096);
-            const u32x4 a1 = *reinterpret_cast<const u32x4*>(wl_w + (size_t)kk * 4096 + 1024);
-            const u32x4 b0 = *reinterpret_cast<const u32x4*>(zf_w + (size_t)kk * 1024);
-            const u32x4 b1 = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(HC_NKK + kk) * 1024);
-            TR::mma16(acc[0][0], a0, b0);
-            TR::mma16(acc[1][0], a1, b0);
-            TR::mma16(acc[0][1], a0, b1);
-            TR::mma16(acc[1][1], a1, b1);
+            for (int j = 0; j < 4; ++j) {
+                bq[j][0] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)j * 1024);
+                bq[j][1] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(HC_NKK + j) * 1024);
+            }
+#pragma unroll
+            for (int kk = 0; kk < HC_NKK; ++kk) {
+                const u32x4 a0 = areg[kk][0], a1 = areg[kk][1];
+                const u32x4 b0 = bq[kk & 3][0], b1 = bq[kk & 3][1];
+                TR::mma16(acc[0][0], a0, b0);
+                TR::mma16(acc[1][0], a1, b0);
+                TR::mma16(acc[0][1], a0, b1);
+                TR::mma16(acc[1][1], a1, b1);
+                if (kk + 4 < HC_NKK) {
+                    bq[kk & 3][0] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(kk + 4) * 1024);
+                    bq[kk & 3][1] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(HC_NKK + kk + 4) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        HC_T(ht1)
         __syncthreads();                                                     // every wave has read the image of step s
         // ---- activation + noise -> operand type; own slice into the image, to the peers, and into E row s + 1 ----
         const uint32_t step_mix = seed_hi ^ ((uint32_t)s * 0x85EBCA6BU + 0x27d4eb2fU);
         const unsigned long long tagb = hc_tag_bits(s % 15 + 1);
+        // (order: image + publish first, THEN everything else that enters this CU's memory queue -- the E rows leave after
+        //  the gather: a hand-off's price sits in the consumer's own queue, and 16 KB of scattered stores ahead of the
+        //  publish and of the polls cost every peer a round trip)
+        uint32_t outw[2][4];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int t = 2 * vc + n;
@@ -246,7 +293,6 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
             const double* nz = nullptr;
             if (NOISE == ESN_NOISE_COUNTER) key = mix32(key1[n] ^ step_mix) + (uint32_t)(16 * c + 8 * vr + g4) * 0x9E3779B9U;
             if (NOISE == ESN_NOISE_TENSOR && fr2[n] >= 0) nz = p.noise_u + ((size_t)fr2[n] * p.S + s) * n_res;
-            uint32_t out[4];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int row = 64 * c + 32 * vr + 16 * tt + 4 * g4;
@@ -264,30 +310,50 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
                     for (int j = 0; j < 4; ++j)
                         if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
                 }
-                out[2 * tt] = TR::pack2(v[0], v[1]);
-                out[2 * tt + 1] = TR::pack2(v[2], v[3]);
-                if (fr2[n] >= 0 && row < n_res) {                            // E holds the ROUNDED state (what the recurrence continues from)
-                    float r[4];
-                    TR::unpack2(out[2 * tt], r[0], r[1]);
-                    TR::unpack2(out[2 * tt + 1], r[2], r[3]);
-                    store_E4(((size_t)fr2[n] * (p.S + 1) + (s + 1)) * ncols + row, r[0], r[1], r[2], r[3]);
-                }
+                outw[n][2 * tt] = TR::pack2(v[0], v[1]);
+                outw[n][2 * tt + 1] = TR::pack2(v[2], v[3]);
             }
-            *reinterpret_cast<u32x4*>(Zf + ((size_t)(t * HC_NKK + 2 * c + vr) * 64 + lane) * 16) = u32x4{out[0], out[1], out[2], out[3]};
+            *reinterpret_cast<u32x4*>(Zf + ((size_t)(t * HC_NKK + 2 * c + vr) * 64 + lane) * 16) =
+                u32x4{outw[n][0], outw[n][1], outw[n][2], outw[n][3]};
             if (s + 1 < p.S) {
                 unsigned long long* dst = xc + ((size_t)((s & 1) * HC_C + c) * 8 + (t * 2 + vr)) * 128 + lane * 2;
-                __hip_atomic_store(dst, ((unsigned long long)out[0] | ((unsigned long long)out[1] << 32)) | tagb,
+                __hip_atomic_store(dst, ((unsigned long long)outw[n][0] | ((unsigned long long)outw[n][1] << 32)) | tagb,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, ((unsigned long long)out[2] | ((unsigned long long)out[3] << 32)) | tagb,
+                __hip_atomic_store(dst + 1, ((unsigned long long)outw[n][2] | ((unsigned long long)outw[n][3] << 32)) | tagb,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (s + 1 == p.S) break;                                             // (the last state is in E; nobody reads it back)
+        // E row s + 1 holds the ROUNDED state (what the recurrence continues from)
+        auto store_rows = [&]() {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int row = 64 * c + 32 * vr + 16 * tt + 4 * g4;
+                    if (fr2[n] >= 0 && row < n_res) {
+                        float r[4];
+                        TR::unpack2(outw[n][2 * tt], r[0], r[1]);
+                        TR::unpack2(outw[n][2 * tt + 1], r[2], r[3]);
+                        store_E4(((size_t)fr2[n] * (p.S + 1) + (s + 1)) * ncols + row, r[0], r[1], r[2], r[3]);
+                    }
+                }
+        };
+        HC_T(ht2)
+        if (s + 1 == p.S) { store_rows(); break; }                           // (the last state is in E; nobody reads it back)
         stage_uf(s + 1, raw_cur);                                            // [U ; F] of step s + 1 (fetched one step ago)
 #pragma unroll
         for (int e = 0; e < 8; ++e) raw_cur[e] = raw_nx[e];
         if (!gather(s)) return;                                              // (ends with a workgroup barrier)
+        HC_T(ht3)
+        store_rows();
+#ifdef ESN_STAMPS
+        hst[0] += ht1 - ht0; hst[1] += ht2 - ht1; hst[2] += ht3 - ht2; hst[3] += hc_polls;
+#endif
     }
+#ifdef ESN_STAMPS
+    if (p.stamps && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 4; ++i) p.stamps[wave * 8 + i] = hst[i];
+#endif
 }
 
 bool harvest_cluster_applies(int precision, const RecurParams& p) {
@@ -297,7 +363,7 @@ bool harvest_cluster_applies(int precision, const RecurParams& p) {
 
 template <typename TR>
 static int launch_hc(const RecurParams& p, int n_clusters, unsigned long long* xch, hipStream_t stream) {
-    const size_t lds = 2 * (size_t)HC_SLICE + 4 * HC_P;
+    const size_t lds = (size_t)HC_SLICE + 4 * HC_P;
     const int grid = 64 * ((n_clusters + 7) / 8);
     auto go = [&](auto kern) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
