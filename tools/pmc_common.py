@@ -42,7 +42,7 @@ def kernel_class(name):
     k = recur_kind(name)
     if k:
         return ("recur_skew16_" if "recur_skew16_kernel" in name else "recur_mfma_") + k
-    for tag in ("recur_rs", "bigh_step", "big_step", "big_prep", "recur_cluster", "readout_chol_big", "recur_f64_mfma", "recur_f64", "readout_chol", "readout_qr", "detect_count", "pack_readout", "pack_weights",
+    for tag in ("harvest_cluster", "recur_rs", "bigh_step", "big_step", "big_prep", "recur_cluster", "readout_chol_big", "recur_f64_mfma", "recur_f64", "readout_chol", "readout_qr", "detect_count", "pack_readout", "pack_weights",
                 "gen_frames", "gen_taps"):
         if tag in name:
             return tag
