@@ -11,7 +11,7 @@ mkdir -p $OUT profiles
 step() { echo "[r03] $1"; }
 
 step "default bench line"
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $OUT/r03_bench_default.json 2> $OUT/bench_default.err || echo "bench failed"
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > profiles/r03_bench_default.json 2> $OUT/bench_default.err || echo "bench failed"
 
 step "headline kernel stats + PMC + stamps"
 timeout -k 10 500 bash tools/profile_round.sh r03 f16 > $OUT/profile_round.log 2>&1 || tail -5 $OUT/profile_round.log
