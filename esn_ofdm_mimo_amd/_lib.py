@@ -9,13 +9,14 @@ LIB_PATH = os.environ.get("ESN_HIP_LIB") or os.path.join(_PKG, "libesn_hip.so") 
 F64, F32, F16, BF16 = 0, 1, 2, 3
 PRECISIONS = {"f64": F64, "f32": F32, "f16": F16, "bf16": BF16}
 NOISE_NONE, NOISE_TENSOR, NOISE_COUNTER = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 MEM_DEVICE, MEM_HOST = 0, 1
 
 
 class Shape(C.Structure):
     _fields_ = [("n_res", C.c_int), ("n_in", C.c_int), ("n_out", C.c_int),
-                ("teacher_forcing", C.c_int), ("n_wsets", C.c_int)]
+                ("teacher_forcing", C.c_int), ("n_wsets", C.c_int),
+                ("leak_rate", C.c_double)]       # extension: 0 or 1 = the reference's update (include/esn_hip.h)
 
 
 class EsnHipError(RuntimeError):

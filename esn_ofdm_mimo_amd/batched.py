@@ -38,7 +38,7 @@ def _as_dev(x, torch, device, dtype=None):
 
 class ReservoirBank:
     def __init__(self, n_inputs, n_outputs, n_reservoir, W, W_in, W_feedb,
-                 teacher_forcing=True, noise=0.001, device=None):
+                 teacher_forcing=True, noise=0.001, device=None, leak_rate=1.0):
         torch = _lib.require_gpu()
         self.torch = torch
         self.lib = _lib.load()
@@ -54,7 +54,10 @@ class ReservoirBank:
         if W.shape[1:] != (n_reservoir, n_reservoir) or W_in.shape != (self.n_wsets, n_reservoir, n_inputs) \
                 or W_feedb.shape != (self.n_wsets, n_reservoir, n_outputs):
             raise ValueError("weight shapes do not match (n_wsets, n_reservoir, ...)")
-        self.shape = Shape(n_reservoir, n_inputs, n_outputs, 1 if teacher_forcing else 0, self.n_wsets)
+        if not 0.0 < float(leak_rate) <= 1.0:
+            raise ValueError("leak_rate must be in (0, 1]")
+        self.leak_rate = float(leak_rate)       # extension (the reference has none): float64 kernels only when != 1
+        self.shape = Shape(n_reservoir, n_inputs, n_outputs, 1 if teacher_forcing else 0, self.n_wsets, self.leak_rate)
         with torch.cuda.device(self.device):
             self._W = _as_dev(W, torch, self.device)
             self._W_in = _as_dev(W_in, torch, self.device)

@@ -184,7 +184,7 @@ extern "C" {
 
 const char* esn_last_error(void) { return g_err; }
 
-int esn_abi_version(void) { return 8; }
+int esn_abi_version(void) { return 9; }
 
 int esn_debug_set(const char* key, const char* value) {
     if (!key) return fail(-1, "esn_debug_set: null key");
@@ -293,6 +293,10 @@ static int fill_common(RecurParams& p, int precision, const esn_shape_t* shape, 
     p.n_wsets = shape->n_wsets;
     p.wset_stride = packed_w_bytes(precision, p.n_res, p.n_in, p.n_out, p.g);
     p.wout_stride = packed_wout_bytes(precision, p.n_res, p.n_in, p.n_out, p.g);
+    p.leak = (shape->leak_rate == 0.0) ? 1.0 : shape->leak_rate;
+    if (!(p.leak > 0.0 && p.leak <= 1.0)) return fail(-1, "%s: leak_rate %g outside (0, 1]", who, shape->leak_rate);
+    if (p.leak != 1.0 && precision != ESN_F64)
+        return fail(-2, "%s: leak_rate != 1 is an extension of the float64 kernels (precision ESN_F64)", who);
     p.w16_off = (size_t)p.g.Mp * p.g.Kp * 2;
     p.wo16_off = wout_big_offset(precision, p.n_out, p.g);
     p.w64_off = f64_w_offset(p.n_res, p.n_in, p.n_out);

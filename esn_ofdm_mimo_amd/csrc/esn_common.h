@@ -64,6 +64,7 @@ struct RecurParams {
     const double* x0; const double* y0;
     const double* noise_u;
     double noise; int noise_mode; uint64_t seed;
+    double leak;           // leak rate a in (0, 1]: x = (1 - a) x_prev + a tanh(.) + noise; 1 = the reference (float64 kernels only)
     uint32_t frame_off;    // counter noise: global index of this launch's frame 0 (= group_offset * F, mod 2^32), so a
                            // frame draws the same noise whichever launch, chunk or rank it lands in
     int wset_rot;          // n_wsets > 1: group g uses weight set (g + wset_rot) % n_wsets (= group_offset % n_wsets)

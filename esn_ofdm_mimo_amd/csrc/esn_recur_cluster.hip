@@ -266,6 +266,7 @@ __global__ __launch_bounds__(CL_NT) void recur_cluster_kernel(RecurParams p, Clu
             const int row = row0 + tid;
             // (wave-uniform vote: the OFDM workload keeps |z| < 0.15, where the 12-instruction series is exact to 2e-18)
             xn = __all(fabs(z) <= TANH64_SERIES_MAX) ? tanh_f64_series(z) : tanh(z);
+            if (p.leak != 1.0 && row < n_res) { const double xo = v[row]; xn = fma(p.leak, xn - xo, xo); }   // (extension)
             if (p.noise_mode == ESN_NOISE_TENSOR && row < n_res)
                 xn += p.noise * (nz_cur - 0.5);
             else if (p.noise_mode == ESN_NOISE_COUNTER)

@@ -142,6 +142,11 @@ __global__ __launch_bounds__(1024) void recur_f64_kernel(RecurParams p) {
             for (int f = 0; f < FB; ++f) {
                 double x0v = tanh(a0[f]);
                 double x1v = tanh(a1[f]);
+                if (p.leak != 1.0) {                       // leaky integration (extension; the reference has a == 1)
+                    const double xo0 = Xc[f * n_res + r0], xo1 = has1 ? Xc[f * n_res + r1] : 0.0;
+                    x0v = fma(p.leak, x0v - xo0, xo0);
+                    x1v = fma(p.leak, x1v - xo1, xo1);
+                }
                 if (p.noise_mode != ESN_NOISE_NONE && s_fr[f] >= 0) {
                     const uint32_t fr = (uint32_t)s_fr[f];
                     double u0, u1 = 0.0;

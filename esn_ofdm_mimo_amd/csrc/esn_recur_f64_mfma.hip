@@ -309,6 +309,7 @@ __global__ __launch_bounds__(512) void recur_f64_mfma_kernel(RecurParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) amax = fmax(amax, fabs(acc[mt][nt][i]));
         const bool small = __all(amax <= TANH64_SERIES_MAX) != 0;   // NaN compares false -> library path
+        const bool leaky = p.leak != 1.0;
         auto activate = [&](auto series_tag) {
             constexpr bool SERIES = decltype(series_tag)::value;
 #pragma unroll
@@ -325,6 +326,10 @@ __global__ __launch_bounds__(512) void recur_f64_mfma_kernel(RecurParams p) {
                     for (int i = 0; i < 4; ++i) {
                         const int row = (w_rt0 + mt) * 16 + q + 4 * i;
                         double x = SERIES ? tanh_f64_series(acc[mt][nt][i]) : tanh(acc[mt][nt][i]);
+                        if (leaky) {                       // (extension; wave-uniform)
+                            const double xo = Zt[(size_t)fcol * g.Ks + row];
+                            x = fma(p.leak, x - xo, xo);
+                        }
                         if (fr >= 0 && row < n_res) {
                             if (p.noise_mode == ESN_NOISE_COUNTER) x += p.noise * ((double)noise_uniform(key, row) - 0.5);
                             else if (p.noise_mode == ESN_NOISE_TENSOR) x += p.noise * (nz[row] - 0.5);

@@ -50,7 +50,7 @@ class ESN:
                  input_scaling=None, teacher_forcing=True, feedback_scaling=None,
                  teacher_scaling=None, teacher_shift=None,
                  out_activation=identity, inverse_out_activation=identity,
-                 random_state=None, silent=True, *, precision="f32", device=None):
+                 random_state=None, silent=True, *, precision="f32", device=None, leak_rate=1.0):
         self.n_inputs = n_inputs
         self.n_reservoir = n_reservoir
         self.n_outputs = n_outputs
@@ -81,6 +81,10 @@ class ESN:
         self.teacher_forcing = teacher_forcing
         self.silent = silent
         self.precision = precision          # kernel used for 3-D (batched) predict
+        # extension (the reference has no leak rate): x[t] = (1-a) x[t-1] + a tanh(...) + noise; float64 only
+        self.leak_rate = float(leak_rate)
+        if self.leak_rate != 1.0:
+            self.precision = "f64"
         self.device = device
         _lib.load()
         _lib.require_gpu()
@@ -101,7 +105,7 @@ class ESN:
         if self._bank is None:
             self._bank = ReservoirBank(self.n_inputs, self.n_outputs, self.n_reservoir, self.W, self.W_in,
                                        self.W_feedb, teacher_forcing=self.teacher_forcing, noise=self.noise,
-                                       device=self.device)
+                                       device=self.device, leak_rate=self.leak_rate)
             ts = None if self.teacher_scaling is None else \
                 np.broadcast_to(np.asarray(self.teacher_scaling, dtype=float), (self.n_outputs,))[None]
             tsh = None if self.teacher_shift is None else \

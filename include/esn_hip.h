@@ -70,6 +70,9 @@ typedef struct esn_shape {
     int n_out;            /* output units (2 N_t)                                    */
     int teacher_forcing;  /* 1: W_feedb term active (pyESN.py:117-120)               */
     int n_wsets;          /* number of (W, W_in, W_feedb) sets: 1 = shared reservoir */
+    double leak_rate;     /* EXTENSION (the reference has none): x[t] = (1-a) x[t-1] + a tanh(...) + noise.
+                             0 (what `{n_res, n_in, n_out, tf, n_wsets}` initialises it to) or 1 = the reference's
+                             update.  Values in (0, 1) are served by ESN_F64 only (other precisions answer -2). */
 } esn_shape_t;
 
 const char* esn_last_error(void);

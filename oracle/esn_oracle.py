@@ -88,13 +88,14 @@ class OracleESN:
                  spectral_radius=0.95, sparsity=0, noise=0.001,
                  input_shift=None, input_scaling=None, teacher_forcing=True,
                  feedback_scaling=None, teacher_scaling=None,
-                 teacher_shift=None, random_state=None, weights=None):
+                 teacher_shift=None, random_state=None, weights=None, leak_rate=1.0):
         self.n_inputs, self.n_outputs, self.n_reservoir = n_inputs, n_outputs, n_reservoir
         self.spectral_radius, self.sparsity, self.noise = spectral_radius, sparsity, noise
         self.input_shift = broadcast_arg(input_shift, n_inputs)
         self.input_scaling = broadcast_arg(input_scaling, n_inputs)
         self.teacher_scaling, self.teacher_shift = teacher_scaling, teacher_shift
         self.teacher_forcing = teacher_forcing
+        self.leak_rate = float(leak_rate)          # extension (BASELINE north_star's formula; the reference is a == 1)
         # pyESN.py:79-87: RandomState instance | truthy seed | global RNG
         if isinstance(random_state, np.random.RandomState):
             self.rng = random_state
@@ -142,7 +143,10 @@ class OracleESN:
         pre = self.W @ x + self.W_in @ u
         if self.teacher_forcing:
             pre = pre + self.W_feedb @ y_prev
-        return np.tanh(pre) + self.noise * (self.rng.rand(self.n_reservoir) - 0.5)
+        act = np.tanh(pre)
+        if self.leak_rate != 1.0:                  # extension: x[t] = (1-a) x[t-1] + a tanh(.)  (+ noise, as the reference adds it)
+            act = x + self.leak_rate * (act - x)
+        return act + self.noise * (self.rng.rand(self.n_reservoir) - 0.5)
 
     # a6 ------------------------------------------------------------------
     def fit(self, inputs, outputs, transient=0):

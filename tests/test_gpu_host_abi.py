@@ -80,7 +80,11 @@ def test_host_arrays_fit_predict_detect(mods, precision, n_res, tol):
         # ---- the device-pointer entry points on the same inputs: bit-identical
         bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=0.0)
         bank.set_scaling(in_scale, None, t_scale, t_shift)
-        E_dev = bank.harvest(u_fit, d_fit, precision=precision, noise_mode="none").cpu().numpy()
+        L.debug_set("hcluster", "0")       # (the host call above lent no workspace: persistent harvest kernel on both sides)
+        try:
+            E_dev = bank.harvest(u_fit, d_fit, precision=precision, noise_mode="none").cpu().numpy()
+        finally:
+            L.debug_set("hcluster", "1")
         assert np.array_equal(E_dev, E)
         bank.set_readout(w_out)
         Y_dev = bank.predict(u, F, T=T, transient=tr, precision=precision, noise_mode="none").cpu().numpy()

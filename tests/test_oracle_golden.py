@@ -240,3 +240,19 @@ def test_legacy_helpfunc_trainer_matches_reference(golden, tag, noise):
         eo.train_mimo_esn_legacy(esn, 1, cfg.min_delay, cfg.max_delay, cfg.cp, cfg.n_sub, cfg.n_t, cfg.n_r,
                                  cfg.isi, g["pilot_y"], g["pilot_x"])
     assert type(ei.value).__name__ == str(g["flag1_error"])
+
+
+def test_leak_rate_extension_reduces_to_the_reference_update():
+    """leak_rate is an extension: a == 1 is bit-for-bit the reference's update, a < 1 blends with the previous state."""
+    rs = np.random.RandomState(3)
+    u, d = rs.randn(25, 2), np.tanh(rs.randn(25, 1))
+    a1 = eo.OracleESN(2, 1, n_reservoir=20, spectral_radius=0.9, noise=0.001, random_state=7)
+    b1 = eo.OracleESN(2, 1, n_reservoir=20, spectral_radius=0.9, noise=0.001, random_state=7, leak_rate=1.0)
+    assert np.array_equal(a1.fit(u, d), b1.fit(u, d))
+    c = eo.OracleESN(2, 1, n_reservoir=20, spectral_radius=0.9, noise=0.0, random_state=7, leak_rate=0.25)
+    c.fit(u, d)
+    x = np.zeros(20)
+    for t in range(1, 4):       # the first rows of the harvested states, by hand
+        pre = c.W @ x + c.W_in @ c.scale_inputs(u)[t] + c.W_feedb @ c.scale_teacher(d)[t - 1]
+        x = 0.75 * x + 0.25 * np.tanh(pre)
+        assert np.allclose(c._ext_states[t, :20], x, rtol=0, atol=1e-15)
