@@ -37,8 +37,8 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
 // esn_harvest_cluster.hip
 bool harvest_cluster_applies(int precision, const RecurParams& p);
-size_t harvest_cluster_workspace_bytes(int n_pilots);
-int launch_harvest_cluster(int precision, const RecurParams& p, void* workspace, hipStream_t stream);
+size_t harvest_cluster_workspace_bytes(int n_pilots, int C);
+int launch_harvest_cluster(int precision, const RecurParams& p, int C, void* workspace, hipStream_t stream);
 // esn_recur_skew16.hip
 int launch_recur_skew16(int precision, const RecurParams& p, hipStream_t stream);
 // esn_pack.hip
@@ -112,7 +112,7 @@ Knobs& knobs() {
         v = getenv("ESN_BIG_NT");
         x.big_nt = (v && v[0] == '4') ? 4 : 2;
         v = getenv("ESN_HCLUSTER");
-        x.hcluster = (v && v[0] == '0') ? 0 : 1;
+        x.hcluster = (v && (v[0] == '0' || v[0] == '4' || v[0] == '8')) ? v[0] - '0' : 1;
         v = getenv("ESN_S16");
         x.s16 = (v && v[0] == '0') ? 0 : 1;
         v = getenv("ESN_BIG_PIPE");
@@ -207,7 +207,10 @@ int esn_debug_set(const char* key, const char* value) {
     if (!strcmp(key, "gen_ko")) { k.gen_ko = value ? atoi(value) : 0; return 0; }
     if (!strcmp(key, "harvest_gemm")) { k.harvest_gemm = (value && value[0] == '1') ? 1 : 0; return 0; }
     if (!strcmp(key, "big_nt")) { k.big_nt = (value && value[0] == '4') ? 4 : 2; return 0; }
-    if (!strcmp(key, "hcluster")) { k.hcluster = (value && value[0] == '0') ? 0 : 1; return 0; }
+    if (!strcmp(key, "hcluster")) {       // "0" off, "4" / "8" members per cluster (A/B), anything else: the default (2)
+        k.hcluster = (value && (value[0] == '0' || value[0] == '4' || value[0] == '8')) ? value[0] - '0' : 1;
+        return 0;
+    }
     if (!strcmp(key, "s16")) { k.s16 = (value && value[0] == '0') ? 0 : 1; return 0; }
     if (!strcmp(key, "big_pipe")) { k.big_pipe = (value && value[0] == '0') ? 0 : 1; return 0; }
     return fail(-1, "esn_debug_set: unknown key '%s'", key);
@@ -402,7 +405,8 @@ size_t esn_harvest_workspace_bytes(int precision, const esn_shape_t* shape, int 
     if (fill_common(p, precision, shape, "esn_harvest_workspace_bytes", true)) return 0;
     p.harvest = 1; p.n_groups = n_groups; p.n_frames = n_groups; p.F = 1;
     if (knobs().cluster && cluster_applies(precision, p)) return cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, true);
-    if (knobs().hcluster && harvest_cluster_applies(precision, p)) return harvest_cluster_workspace_bytes(n_groups);
+    if (knobs().hcluster && harvest_cluster_applies(precision, p))
+        return harvest_cluster_workspace_bytes(n_groups, knobs().hcluster == 1 ? 2 : knobs().hcluster);
     if (!big_harvest_applies(precision, p)) return 0;
     return big_harvest_workspace_bytes(n_groups, p.g.Kp);
 }
@@ -456,11 +460,12 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     }
     // 257..512 units, fp16/bf16, shared reservoir: clusters of eight workgroups with the matrix resident in LDS
     if (workspace && knobs().hcluster && harvest_cluster_applies(precision, p)) {
-        const size_t need = harvest_cluster_workspace_bytes(n_groups);
+        const int hc_c = knobs().hcluster == 1 ? 2 : knobs().hcluster;           // members per cluster
+        const size_t need = harvest_cluster_workspace_bytes(n_groups, hc_c);
         if (workspace_bytes < need)
             return fail(-1, "esn_harvest_batch: workspace holds %zu bytes, esn_harvest_workspace_bytes says %zu",
                         workspace_bytes, need);
-        return hip_fail(launch_harvest_cluster(precision, p, workspace, (hipStream_t)stream), "esn_harvest_batch");
+        return hip_fail(launch_harvest_cluster(precision, p, hc_c, workspace, (hipStream_t)stream), "esn_harvest_batch");
     }
     // large reservoirs: one GEMM launch per step when the caller lends a workspace (else the persistent kernel)
     if (workspace && knobs().big_gemm && big_harvest_applies(precision, p)) {

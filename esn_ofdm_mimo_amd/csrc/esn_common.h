@@ -218,8 +218,8 @@ struct Knobs {
     int harvest_gemm;      // 1: harvests of 257..1024 units (>= 64 pilots) also take the GEMM-per-step path (A/B; slower)
     int gen_ko;            // frame generator knock-out mask for tools/time_gen.py (timing only, wrong frames)
     int s16;               // 1 (default): fp16/bf16 predict at 257..512 units on the 16x16x32 kernel; 0: the 32x32x16 one (A/B)
-    int hcluster;          // 1 (default): fp16/bf16 harvest at 257..512 units on the LDS-resident cluster kernel when a
-                           // workspace is given; 0: the persistent kernel (A/B)
+    int hcluster;          // 1 (default): fp16/bf16 harvest at 257..512 units on the cluster kernel (two members per cluster)
+                           // when a workspace is given; 4 / 8: that many members (A/B); 0: the persistent kernel
 };
 Knobs& knobs();
 

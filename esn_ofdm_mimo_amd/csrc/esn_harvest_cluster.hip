@@ -24,18 +24,18 @@
 
 namespace esn {
 
-constexpr int HC_C = 8;                           // workgroups per cluster = row slices of 64
-constexpr int HC_P = 64;                          // pilots per cluster = 4 column tiles of 16
-constexpr int HC_NT = 256;                        // 4 waves: (row-tile pair vr) x (pilot-tile pair vc)
+// Cluster shapes: C workgroups (row slices of 512 / C rows) own P = 8 C pilots -- every member publishes 8 KB per step
+// whatever C is, and gathers (C - 1) x 8 KB.  C = 2 (256 rows and 16 pilots per workgroup, ONE peer, 8 KB gathered) is
+// the default: the step is the hand-off, and the hand-off is its bytes.  C = 8 (64 rows x 64 pilots, 56 KB gathered:
+// the first version) and C = 4 stay instantiated for A/B runs (debug knob hcluster = 8 / 4).
+constexpr int HC_NT = 256;                        // 4 waves: NWR row groups x NWC pilot-tile groups
 constexpr int HC_NKK = 17;
-constexpr int HC_SLICE = HC_NKK * 4 * 1024;       // bytes of a workgroup's weight slice and of its state image
-constexpr int HC_NG = 14;                         // 16-byte chunks a thread gathers per step: 7 x 8 x 64 / 256
 constexpr uint32_t HC_SPIN_LIMIT = 1u << 22;
 constexpr unsigned long long HC_TAGMASK = 0x4000400040004000ULL;
 
-static inline int hc_clusters(int n_pilots) { return (n_pilots + HC_P - 1) / HC_P; }
-size_t harvest_cluster_workspace_bytes(int n_pilots) {
-    return (size_t)hc_clusters(n_pilots) * 2 * HC_C * 8 * 1024 + 64;         // two parities x 8 members x 8 KB, + error word
+static inline int hc_clusters(int n_pilots, int C) { return (n_pilots + 8 * C - 1) / (8 * C); }
+size_t harvest_cluster_workspace_bytes(int n_pilots, int C) {
+    return (size_t)hc_clusters(n_pilots, C) * 2 * C * 8 * 1024 + 64;        // two parities x C members x 8 KB, + error word
 }
 
 __device__ __forceinline__ unsigned long long hc_tag_bits(int tag) {         // tag 1..15 -> bit 14 of each of four halves
@@ -43,45 +43,54 @@ __device__ __forceinline__ unsigned long long hc_tag_bits(int tag) {         // 
            ((unsigned long long)((tag >> 2) & 1) << 46) | ((unsigned long long)((tag >> 3) & 1) << 62);
 }
 
-template <typename TR, int NOISE>
+template <typename TR, int NOISE, int C>
 __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, int n_clusters, unsigned long long* xch) {
+    constexpr int ROWS = 512 / C;                  // rows of Wext per member
+    constexpr int RT = ROWS / 16, CT = C / 2;      // 16-row tiles per member, 16-pilot tiles per cluster
+    constexpr int P = 16 * CT;                     // pilots per cluster
+    constexpr int NWC = CT < 2 ? CT : 2, NWR = 4 / NWC;
+    constexpr int WR = RT / NWR, WC = CT / NWC;    // row tiles x pilot tiles per wave
+    constexpr int KPM = ROWS / 32;                 // 32-k groups a member produces (blocks per pilot tile it publishes)
+    constexpr int NG = (C - 1) * 2;                // 16-byte chunks a thread gathers per step
+    constexpr int ZF_BYTES = CT * HC_NKK * 1024;
+    static_assert(RT % NWR == 0 && WR % 2 == 0 && CT * KPM == 8, "cluster shape");
     extern __shared__ __attribute__((aligned(16))) char hsm[];
     char* Zf = hsm;                                // [tile][kk][lane][16 B]
-    int* tab_fr = reinterpret_cast<int*>(Zf + HC_SLICE);                   // [64] pilot (= frame) index or -1
     __shared__ int sh_dead;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int vr = wave >> 1, vc = wave & 1;
+    const int vr = wave / NWC, vc = wave % NWC;
     const int g4 = lane >> 4, col = lane & 15;
     const int lane16 = lane * 16;
     const Geometry& g = p.g;
     const int n_res = p.n_res, n_in = p.n_in, n_out = p.n_out;
     const int kin_p = g.kfb - g.kin;
     const int ncols = n_res + n_in;
-    // block -> (cluster, member): the eight members of a cluster are consecutive blocks of ONE XCD (block id mod 8)
+    // block -> (cluster, member): the members of a cluster are consecutive blocks of ONE XCD (block id mod 8)
     const int cpx = (n_clusters + 7) / 8;                                   // clusters per XCD
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    const int cluster = xcd * cpx + (li >> 3), c = li & 7;
+    const int cluster = xcd * cpx + li / C, c = li % C;
     if (cluster >= n_clusters) return;                                      // (a whole cluster leaves together)
-    unsigned int* err = reinterpret_cast<unsigned int*>(xch + (size_t)n_clusters * 2 * HC_C * 1024);
-    unsigned long long* xc = xch + (size_t)cluster * 2 * HC_C * 1024;        // [parity][member][block][lane][2]
+    unsigned int* err = reinterpret_cast<unsigned int*>(xch + (size_t)n_clusters * 2 * C * 1024);
+    unsigned long long* xc = xch + (size_t)cluster * 2 * C * 1024;           // [parity][member][block][lane][2]
     if (tid == 0) sh_dead = 0;
 
-    // ---- resident operands: the wave's 2 row tiles x 17 groups of weight fragments live in REGISTERS for the whole
-    // launch (136 of the 512 a lone wave per SIMD may hold): slice c of the 16x16x32 image, fragment (kk, m) at
-    // ((c NKK + kk) 4 + m) KB.  Only the state image is in LDS.
-    u32x4 areg[HC_NKK][2];
+    // ---- resident operands: the wave's WR row tiles x 17 groups of weight fragments live in REGISTERS for the whole
+    // launch (136 or 272 of the 512 a lone wave per SIMD may hold): global row tile grt = c RT + vr WR + i of the 16x16x32
+    // image, fragment (kk, grt) at (((grt / 4) NKK + kk) 4 + grt % 4) KB.  Only the state image is in LDS.
+    u32x4 areg[HC_NKK][WR];
     {
-        const char* src = reinterpret_cast<const char*>(p.packed_w) + p.w16_off + (size_t)c * HC_SLICE + (size_t)(2 * vr) * 1024 + lane16;
+        const char* src = reinterpret_cast<const char*>(p.packed_w) + p.w16_off + lane16;
 #pragma unroll
-        for (int kk = 0; kk < HC_NKK; ++kk) {
-            areg[kk][0] = *reinterpret_cast<const u32x4*>(src + (size_t)kk * 4096);
-            areg[kk][1] = *reinterpret_cast<const u32x4*>(src + (size_t)kk * 4096 + 1024);
-        }
-        for (int i = tid; i < HC_SLICE / 16; i += HC_NT) reinterpret_cast<u32x4*>(Zf)[i] = u32x4{0, 0, 0, 0};   // X_0 = 0
+        for (int kk = 0; kk < HC_NKK; ++kk)
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                const int grt = c * RT + vr * WR + i;
+                areg[kk][i] = *reinterpret_cast<const u32x4*>(src + ((size_t)((grt >> 2) * HC_NKK + kk) * 4 + (grt & 3)) * 1024);
+            }
+        for (int i = tid; i < ZF_BYTES / 16; i += HC_NT) reinterpret_cast<u32x4*>(Zf)[i] = u32x4{0, 0, 0, 0};   // X_0 = 0
     }
-    const int pil0 = cluster * HC_P;
-    if (tid < HC_P) tab_fr[tid] = (pil0 + tid < p.n_groups) ? pil0 + tid : -1;
+    const int pil0 = cluster * P;
     auto store_E4 = [&](size_t idx, float v0, float v1, float v2, float v3) {      // idx multiple of 4
         if (p.E32) {
             *reinterpret_cast<f32x4*>(p.E32 + idx) = f32x4{v0, v1, v2, v3};
@@ -93,9 +102,10 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     };
     // ---- [U ; F] staging: thread (pilot f = tid & 63, chunk q = tid >> 6) builds the eight positions 8 q .. 8 q + 7
     // of the [U ; F] group of its pilot: inputs row s + 1 scaled (pyESN.py:180-182), teacher row s scaled
-    const int sf = tid & 63, sq = tid >> 6;
+    const int sf = tid & (P - 1), sq = (tid / P) & 3;
+    const bool s_thr = tid < 4 * P;                                          // (C < 8: fewer staging threads than the block has)
     const int s_pil = pil0 + sf;
-    const bool s_ok = s_pil < p.n_groups;
+    const bool s_ok = s_thr && s_pil < p.n_groups;
     double uf_sc[8], uf_sh[8];
     int uf_kind[8];                                                          // 0 = zero, 1 = input, 2 = teacher
 #pragma unroll
@@ -137,8 +147,9 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
         for (int e = 0; e < 8; ++e) sv[e] = uf_kind[e] ? raw[e] * uf_sc[e] + uf_sh[e] : 0.0;      // as the persistent kernel
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = TR::pack2((float)sv[2 * e], (float)sv[2 * e + 1]);
-        *reinterpret_cast<u32x4*>(Zf + ((size_t)((sf >> 4) * HC_NKK + 16) * 64 + sq * 16 + (sf & 15)) * 16) =
-            u32x4{out[0], out[1], out[2], out[3]};
+        if (s_thr)
+            *reinterpret_cast<u32x4*>(Zf + ((size_t)((sf >> 4) * HC_NKK + 16) * 64 + sq * 16 + (sf & 15)) * 16) =
+                u32x4{out[0], out[1], out[2], out[3]};
         if (c == 0 && s_ok && 8 * sq < n_in) {
             const size_t e0 = ((size_t)s_pil * (p.S + 1) + (s + 1)) * ncols + n_res + 8 * sq;
 #pragma unroll
@@ -167,12 +178,12 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
 
     const float noise = (float)p.noise;
     const float n_c1 = noise * (1.0f / 256.0f), n_c0 = noise * (0.5f / 256.0f - 0.5f);
-    // the two pilots of this lane (tiles 2 vc, 2 vc + 1, column col): frame index and step-independent key half
-    int fr2[2];
-    uint32_t key1[2];
+    // the WC pilots of this lane (tiles vc WC + n, column col): frame index and step-independent key half
+    int fr2[WC];
+    uint32_t key1[WC];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int pl = pil0 + (2 * vc + n) * 16 + col;
+    for (int n = 0; n < WC; ++n) {
+        const int pl = pil0 + (vc * WC + n) * 16 + col;
         fr2[n] = pl < p.n_groups ? pl : -1;
         key1[n] = mix32((uint32_t)p.seed ^ (((uint32_t)pl + p.frame_off) * 0x9E3779B9U));
     }
@@ -182,41 +193,41 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
 #ifdef ESN_STAMPS
     unsigned long long hc_polls = 0;
 #endif
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(xc), 0, 2 * HC_C * 8192, 0x00020000);
-    // gather the seven other members' slices of X_{s+1} (tag of step s) into the state image; false on time-out
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(xc), 0, 2 * C * 8192, 0x00020000);
+    // gather the other members' slices of X_{s+1} (tag of step s) into the state image; false on time-out
     auto gather = [&](int s) -> bool {
         const int par = s & 1;
         const unsigned long long want = hc_tag_bits(s % 15 + 1);
-        unsigned pending = (1u << HC_NG) - 1;
+        unsigned pending = (1u << NG) - 1;
         uint32_t spins = 0;
 #ifdef ESN_STAMPS
         hc_polls = 0;
 #endif
         bool ok = true;
         while (pending) {
-            unsigned long long lo[HC_NG], hi[HC_NG];
+            unsigned long long lo[NG], hi[NG];
 #ifdef ESN_STAMPS
             ++hc_polls;
 #endif
             // one 16-byte agent-scope (sc1) load per chunk: each 8-byte half carries its own tag, so a torn pair is
             // simply not accepted yet
 #pragma unroll
-            for (int j = 0; j < HC_NG; ++j)
+            for (int j = 0; j < NG; ++j)
                 if (pending & (1u << j)) {
                     const int ch = tid + j * HC_NT;                          // chunk: peer (ch >> 9), block, lane
-                    const int cp = (c + 1 + (ch >> 9)) & 7;
-                    const int off = (((par * HC_C + cp) * 8 + ((ch >> 6) & 7)) * 64 + (ch & 63)) * 16;
+                    const int cp = (c + 1 + (ch >> 9)) & (C - 1);
+                    const int off = (((par * C + cp) * 8 + ((ch >> 6) & 7)) * 64 + (ch & 63)) * 16;
                     const u32x4 w = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 16));
                     lo[j] = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
                     hi[j] = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
                 }
 #pragma unroll
-            for (int j = 0; j < HC_NG; ++j)
+            for (int j = 0; j < NG; ++j)
                 if ((pending & (1u << j)) && (lo[j] & HC_TAGMASK) == want && (hi[j] & HC_TAGMASK) == want) {
                     const int ch = tid + j * HC_NT;
-                    const int cp = (c + 1 + (ch >> 9)) & 7, blk = (ch >> 6) & 7, ln = ch & 63;
+                    const int cp = (c + 1 + (ch >> 9)) & (C - 1), blk = (ch >> 6) & 7, ln = ch & 63;
                     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-                    *reinterpret_cast<u64x2*>(Zf + ((size_t)((blk >> 1) * HC_NKK + 2 * cp + (blk & 1)) * 64 + ln) * 16) =
+                    *reinterpret_cast<u64x2*>(Zf + ((size_t)((blk / KPM) * HC_NKK + KPM * cp + blk % KPM) * 64 + ln) * 16) =
                         u64x2{lo[j] & ~HC_TAGMASK, hi[j] & ~HC_TAGMASK};
                     pending &= ~(1u << j);
                 }
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
         return sh_dead == 0;
     };
 
-    const char* zf_w = Zf + (size_t)(2 * vc) * HC_NKK * 1024 + lane16;        // tiles 2 vc, 2 vc + 1
+    const char* zf_w = Zf + (size_t)(vc * WC) * HC_NKK * 1024 + lane16;        // the wave's pilot tiles
 #ifdef ESN_STAMPS
     unsigned long long hst[4] = {0, 0, 0, 0};
 #define HC_T(v) const unsigned long long v = __builtin_amdgcn_s_memrealtime();
@@ -247,32 +258,30 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     for (int s = 0; s < p.S; ++s) {
         HC_T(ht0)
         fetch_uf(s + 2, raw_nx);                                             // two steps ahead of its use (see stage_uf below)
-        // ---- P[64 x 64] = Wext[rows of c] * [X_s ; U ; F]: wave (vr, vc) takes 2 row tiles x 2 pilot tiles ----
-        f32x4 acc[2][2];
+        // ---- P = Wext[rows of c] * [X_s ; U ; F]: wave (vr, vc) takes WR row tiles x WC pilot tiles ----
+        f32x4 acc[WR][WC];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < WR; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < WC; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         // state fragments four groups ahead in a ring of registers (left to itself the compiler reads one group at a
         // time into the same registers and waits for it: 17 exposed LDS latencies per step)
         {
-            u32x4 bq[4][2];
+            u32x4 bq[4][WC];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bq[j][0] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)j * 1024);
-                bq[j][1] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(HC_NKK + j) * 1024);
-            }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < WC; ++n) bq[j][n] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(n * HC_NKK + j) * 1024);
 #pragma unroll
             for (int kk = 0; kk < HC_NKK; ++kk) {
-                const u32x4 a0 = areg[kk][0], a1 = areg[kk][1];
-                const u32x4 b0 = bq[kk & 3][0], b1 = bq[kk & 3][1];
-                TR::mma16(acc[0][0], a0, b0);
-                TR::mma16(acc[1][0], a1, b0);
-                TR::mma16(acc[0][1], a0, b1);
-                TR::mma16(acc[1][1], a1, b1);
+#pragma unroll
+                for (int n = 0; n < WC; ++n)
+#pragma unroll
+                    for (int m = 0; m < WR; ++m) TR::mma16(acc[m][n], areg[kk][m], bq[kk & 3][n]);
                 if (kk + 4 < HC_NKK) {
-                    bq[kk & 3][0] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(kk + 4) * 1024);
-                    bq[kk & 3][1] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(HC_NKK + kk + 4) * 1024);
+#pragma unroll
+                    for (int n = 0; n < WC; ++n)
+                        bq[kk & 3][n] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(n * HC_NKK + kk + 4) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -283,57 +292,61 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
         const uint32_t step_mix = seed_hi ^ ((uint32_t)s * 0x85EBCA6BU + 0x27d4eb2fU);
         const unsigned long long tagb = hc_tag_bits(s % 15 + 1);
         // (order: image + publish first, THEN everything else that enters this CU's memory queue -- the E rows leave after
-        //  the gather: a hand-off's price sits in the consumer's own queue, and 16 KB of scattered stores ahead of the
-        //  publish and of the polls cost every peer a round trip)
-        uint32_t outw[2][4];
+        //  the gather)
+        uint32_t outw[WC][WR / 2][4];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int t = 2 * vc + n;
+        for (int n = 0; n < WC; ++n) {
+            const int t = vc * WC + n;
             uint32_t key = 0;
             const double* nz = nullptr;
-            if (NOISE == ESN_NOISE_COUNTER) key = mix32(key1[n] ^ step_mix) + (uint32_t)(16 * c + 8 * vr + g4) * 0x9E3779B9U;
+            if (NOISE == ESN_NOISE_COUNTER) key = mix32(key1[n] ^ step_mix) + (uint32_t)((ROWS * c + 16 * WR * vr) / 4 + g4) * 0x9E3779B9U;
             if (NOISE == ESN_NOISE_TENSOR && fr2[n] >= 0) nz = p.noise_u + ((size_t)fr2[n] * p.S + s) * n_res;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int row = 64 * c + 32 * vr + 16 * tt + 4 * g4;
-                float v[4];
+            for (int pr = 0; pr < WR / 2; ++pr) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[tt][n][j]);
-                if (NOISE == ESN_NOISE_COUNTER) {
-                    const uint32_t sq4 = noise_mix(key + (uint32_t)(4 * tt) * 0x9E3779B9U);
-                    v[0] = fmaf((float)(sq4 & 0xffU), n_c1, v[0] + n_c0);
-                    v[1] = fmaf((float)((sq4 >> 8) & 0xffU), n_c1, v[1] + n_c0);
-                    v[2] = fmaf((float)((sq4 >> 16) & 0xffU), n_c1, v[2] + n_c0);
-                    v[3] = fmaf((float)(sq4 >> 24), n_c1, v[3] + n_c0);
-                } else if (NOISE == ESN_NOISE_TENSOR) {
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int m = 2 * pr + tt;
+                    const int row = ROWS * c + 16 * (WR * vr + m) + 4 * g4;
+                    float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+                    for (int j = 0; j < 4; ++j) v[j] = TR::act(acc[m][n][j]);
+                    if (NOISE == ESN_NOISE_COUNTER) {
+                        const uint32_t sq4 = noise_mix(key + (uint32_t)(4 * m) * 0x9E3779B9U);
+                        v[0] = fmaf((float)(sq4 & 0xffU), n_c1, v[0] + n_c0);
+                        v[1] = fmaf((float)((sq4 >> 8) & 0xffU), n_c1, v[1] + n_c0);
+                        v[2] = fmaf((float)((sq4 >> 16) & 0xffU), n_c1, v[2] + n_c0);
+                        v[3] = fmaf((float)(sq4 >> 24), n_c1, v[3] + n_c0);
+                    } else if (NOISE == ESN_NOISE_TENSOR) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (nz && row + j < n_res) v[j] += noise * ((float)nz[row + j] - 0.5f);
+                    }
+                    outw[n][pr][2 * tt] = TR::pack2(v[0], v[1]);
+                    outw[n][pr][2 * tt + 1] = TR::pack2(v[2], v[3]);
                 }
-                outw[n][2 * tt] = TR::pack2(v[0], v[1]);
-                outw[n][2 * tt + 1] = TR::pack2(v[2], v[3]);
-            }
-            *reinterpret_cast<u32x4*>(Zf + ((size_t)(t * HC_NKK + 2 * c + vr) * 64 + lane) * 16) =
-                u32x4{outw[n][0], outw[n][1], outw[n][2], outw[n][3]};
-            if (s + 1 < p.S) {
-                unsigned long long* dst = xc + ((size_t)((s & 1) * HC_C + c) * 8 + (t * 2 + vr)) * 128 + lane * 2;
-                __hip_atomic_store(dst, ((unsigned long long)outw[n][0] | ((unsigned long long)outw[n][1] << 32)) | tagb,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, ((unsigned long long)outw[n][2] | ((unsigned long long)outw[n][3] << 32)) | tagb,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int kkl = (WR * vr) / 2 + pr;                          // the member's own group index, < KPM
+                *reinterpret_cast<u32x4*>(Zf + ((size_t)(t * HC_NKK + KPM * c + kkl) * 64 + lane) * 16) =
+                    u32x4{outw[n][pr][0], outw[n][pr][1], outw[n][pr][2], outw[n][pr][3]};
+                if (s + 1 < p.S) {
+                    unsigned long long* dst = xc + ((size_t)((s & 1) * C + c) * 8 + (t * KPM + kkl)) * 128 + lane * 2;
+                    __hip_atomic_store(dst, ((unsigned long long)outw[n][pr][0] | ((unsigned long long)outw[n][pr][1] << 32)) | tagb,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, ((unsigned long long)outw[n][pr][2] | ((unsigned long long)outw[n][pr][3] << 32)) | tagb,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         // E row s + 1 holds the ROUNDED state (what the recurrence continues from)
         auto store_rows = [&]() {
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < WC; ++n)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int row = 64 * c + 32 * vr + 16 * tt + 4 * g4;
+                for (int m = 0; m < WR; ++m) {
+                    const int row = ROWS * c + 16 * (WR * vr + m) + 4 * g4;
                     if (fr2[n] >= 0 && row < n_res) {
                         float r[4];
-                        TR::unpack2(outw[n][2 * tt], r[0], r[1]);
-                        TR::unpack2(outw[n][2 * tt + 1], r[2], r[3]);
+                        TR::unpack2(outw[n][m >> 1][2 * (m & 1)], r[0], r[1]);
+                        TR::unpack2(outw[n][m >> 1][2 * (m & 1) + 1], r[2], r[3]);
                         store_E4(((size_t)fr2[n] * (p.S + 1) + (s + 1)) * ncols + row, r[0], r[1], r[2], r[3]);
                     }
                 }
@@ -361,10 +374,10 @@ bool harvest_cluster_applies(int precision, const RecurParams& p) {
            p.n_groups >= 1 && (p.n_res % 4) == 0 && (p.n_res + p.n_in) % 4 == 0;
 }
 
-template <typename TR>
+template <typename TR, int C>
 static int launch_hc(const RecurParams& p, int n_clusters, unsigned long long* xch, hipStream_t stream) {
-    const size_t lds = (size_t)HC_SLICE + 4 * HC_P;
-    const int grid = 64 * ((n_clusters + 7) / 8);
+    const size_t lds = (size_t)(C / 2) * HC_NKK * 1024;
+    const int grid = 8 * ((n_clusters + 7) / 8) * C;
     auto go = [&](auto kern) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -372,19 +385,22 @@ static int launch_hc(const RecurParams& p, int n_clusters, unsigned long long* x
         return (int)hipGetLastError();
     };
     switch (p.noise_mode) {
-        case ESN_NOISE_NONE: return go(harvest_cluster_kernel<TR, ESN_NOISE_NONE>);
-        case ESN_NOISE_TENSOR: return go(harvest_cluster_kernel<TR, ESN_NOISE_TENSOR>);
-        default: return go(harvest_cluster_kernel<TR, ESN_NOISE_COUNTER>);
+        case ESN_NOISE_NONE: return go(harvest_cluster_kernel<TR, ESN_NOISE_NONE, C>);
+        case ESN_NOISE_TENSOR: return go(harvest_cluster_kernel<TR, ESN_NOISE_TENSOR, C>);
+        default: return go(harvest_cluster_kernel<TR, ESN_NOISE_COUNTER, C>);
     }
 }
 
-int launch_harvest_cluster(int precision, const RecurParams& p, void* workspace, hipStream_t stream) {
-    const int n_clusters = hc_clusters(p.n_groups);
-    hipError_t e = hipMemsetAsync(workspace, 0, harvest_cluster_workspace_bytes(p.n_groups), stream);   // tags start at 1
+// C = members per cluster: 2 (default), 4 or 8
+int launch_harvest_cluster(int precision, const RecurParams& p, int C, void* workspace, hipStream_t stream) {
+    const int n_clusters = hc_clusters(p.n_groups, C);
+    hipError_t e = hipMemsetAsync(workspace, 0, harvest_cluster_workspace_bytes(p.n_groups, C), stream);   // tags start at 1
     if (e != hipSuccess) return (int)e;
     unsigned long long* xch = reinterpret_cast<unsigned long long*>(workspace);
-    if (precision == ESN_F16) return launch_hc<TraitsF16>(p, n_clusters, xch, stream);
-    if (precision == ESN_BF16) return launch_hc<TraitsBF16>(p, n_clusters, xch, stream);
+#define HC_CASE(TRv, Cv) if (C == Cv) return launch_hc<TRv, Cv>(p, n_clusters, xch, stream);
+    if (precision == ESN_F16) { HC_CASE(TraitsF16, 2) HC_CASE(TraitsF16, 4) HC_CASE(TraitsF16, 8) }
+    if (precision == ESN_BF16) { HC_CASE(TraitsBF16, 2) HC_CASE(TraitsBF16, 4) HC_CASE(TraitsBF16, 8) }
+#undef HC_CASE
     return -1;
 }
 

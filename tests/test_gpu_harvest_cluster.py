@@ -40,7 +40,7 @@ def test_cluster_harvest_matches_persistent_kernel_and_oracle(mods, n_res, n_in,
     kw = dict(precision="f16", noise_mode=noise_mode, seed=5, group_offset=3)
     if noise_mode == "tensor":
         kw["noise_u"] = rs.rand(G, t - 1, n_res)
-    assert L.load().esn_harvest_workspace_bytes(L.F16, C.byref(bank.shape), G) == ((G + 63) // 64) * 131072 + 64
+    assert L.load().esn_harvest_workspace_bytes(L.F16, C.byref(bank.shape), G) == ((G + 15) // 16) * 32768 + 64
     e32 = bank.harvest(u, d, e_dtype="f32", **kw)
     bank.raise_if_harvest_timed_out()
     e64 = bank.harvest(u, d, **kw)
