@@ -1,23 +1,23 @@
 // Batched state harvest of ESN.fit (pyESN.py:176-182) at 257..512 reservoir units, fp16 / bf16, with the reservoir
-// matrix RESIDENT IN LDS.
+// matrix RESIDENT ON CHIP.
 //
 // A fit has ONE training sequence per trained ESN (2048 pilots at the benchmark size where predict has 153 600
 // frames).  The persistent harvest kernel (esn_recur_mfma_impl.h, HARVEST) gives a tile of 32 pilots to one workgroup,
 // which re-streams the whole 557 KB weight image from L2 every timestep: 64 workgroups on 256 CUs, each bound by its
 // CU's L2 port (19 k cycles per step, 5 % of the MFMA peak); more, smaller tiles only multiply the aggregate stream
-// (DESIGN 3.1).  Here a CLUSTER of eight co-resident workgroups owns 64 pilots for all T - 1 steps: workgroup c keeps
-// rows [64 c, 64 c + 64) of Wext = [W | W_in | W_feedb] in its LDS (69.6 KB: slice c of the 16x16x32 weight image of
-// esn_pack_weights, as it is) next to the fragment-major state image of its 64 pilots (69.6 KB, the layout of
-// esn_recur_skew16_impl.h), and per step
-//     multiplies  its 64 rows x 64 pilots x 544 k on v_mfma_f32_16x16x32 (4 waves of 2 x 2 tiles, 68 MFMAs each),
+// (DESIGN 3.1).  Here a CLUSTER of C co-resident workgroups owns 8 C pilots for all T - 1 steps: member c keeps rows
+// [512 c / C, 512 (c + 1) / C) of Wext = [W | W_in | W_feedb] -- fragments of the 16x16x32 weight image of
+// esn_pack_weights, as they are -- in REGISTERS, the fragment-major state image of the cluster's pilots in LDS (the
+// layout of esn_recur_skew16_impl.h), and per step
+//     multiplies  its rows x the pilots x 544 k on v_mfma_f32_16x16x32 (4 waves, 68 MFMAs each),
 //     activates   (tanh + state noise -> operand type), stores its rows of E[:, s + 1],
-//     publishes   its 8 KB slice of X_{s+1} and gathers the seven others' -- nothing else moves: no weight traffic.
+//     publishes   its 8 KB slice of X_{s+1} and gathers the other C - 1 -- nothing else moves: no weight traffic.
 // The hand-off is the data-tagged granule form of esn_recur_cluster.hip: an 8-byte granule carries four state values
 // AND the step tag, in the one bit of every half that |x| < 2 leaves free (bit 14: tanh + noise never reaches 2), is
 // written by one agent-scope store and polled by agent-scope loads until the tag reads the awaited step; two
 // buffers by step parity; every spin is bounded (a timed-out workgroup raises the error word in the last 64 bytes of
-// the workspace and leaves, and so does everybody else).  Clusters are laid out so that their eight workgroups
-// share an XCD (block id mod 8), i.e. one L2.
+// the workspace and leaves, and so does everybody else).  Clusters are laid out so that their members are consecutive
+// blocks of one XCD (block id mod 8).
 // Arithmetic, noise stream (counter noise keyed by (seed, global pilot, step, row)) and the rounding of the states to
 // the operand type are those of the persistent harvest kernel; only the summation order inside a dot product differs.
 #include "esn_recur_mfma_impl.h"

@@ -98,6 +98,9 @@ int esn_abi_version(void);
  *   "big_pipe"      "0" = N_res > 1024 predict with the round-2 main loop (two buffers, two barriers per chunk)
  *   "big_nt"        "4" = N_res > 1024 predict on the 4-wave 128 x 128 variant (slower; A/B runs)
  *   "harvest_gemm"  "1" = harvests of 257..1024 units (>= 64 pilots) on the GEMM-per-step path (slower; A/B runs)
+ *   "hcluster"      "0" = fp16/bf16 harvest at 257..512 units on the persistent kernel even when a workspace is given;
+ *                   "4" / "8" = clusters of that many workgroups instead of pairs (esn_harvest_cluster.hip; A/B runs).
+ *                   esn_harvest_workspace_bytes follows the knob: ask for the size after setting it
  *   "gen_ko"        frame-generator knock-out mask for tools/time_gen.py (timing only, wrong frames)
  * Returns 0, or -1 for an unknown key. */
 int esn_debug_set(const char* key, const char* value);
@@ -177,9 +180,13 @@ int esn_predict_batch(int precision, const esn_shape_t* shape,
  *   noise_u [n_groups][T-1][n_res] when noise_mode == ESN_NOISE_TENSOR.
  *   group_offset: as in esn_predict_batch (noise key and weight set follow the GLOBAL group index);
  *   E is 16-byte aligned.
- *   workspace: device scratch of esn_harvest_workspace_bytes(...) bytes, or NULL.  As for predict, only reservoirs
- *   beyond 1024 units in fp16/bf16 use it (one tiled GEMM launch per timestep, 128 x 64 tiles: a fit has one
- *   sequence per trained ESN, so the tile is cut for workgroup count); with NULL the persistent kernel runs.
+ *   workspace: device scratch of esn_harvest_workspace_bytes(...) bytes, or NULL.  Three shapes use it: reservoirs
+ *   beyond 1024 units in fp16/bf16 (one tiled GEMM launch per timestep, 128 x 64 tiles: a fit has one sequence per
+ *   trained ESN, so the tile is cut for workgroup count); fp16/bf16 at 257..512 units with a shared reservoir (pairs
+ *   of co-resident workgroups keep the weight matrix in registers and exchange their state slices through the
+ *   workspace every step, esn_harvest_cluster.hip; its last 64 bytes hold an error word that is non-zero if a
+ *   workgroup timed out waiting for its peer: the states are then invalid); and ONE float64 sequence (the cluster
+ *   kernel of esn_predict_batch).  With NULL the persistent kernels run.
  *   precision: ESN_F64 / ESN_F32 keep the states at (better than) float32; ESN_F16 / ESN_BF16
  *   harvest states rounded to the operand type (round-off ~6e-6 abs, far below the model's own
  *   state noise 2.9e-4 rms) -- statistically equivalent, not bit-comparable.
