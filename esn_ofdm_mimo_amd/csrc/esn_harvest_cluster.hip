@@ -53,6 +53,12 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     constexpr int KPM = ROWS / 32;                 // 32-k groups a member produces (blocks per pilot tile it publishes)
     constexpr int NG = (C - 1) * 2;                // 16-byte chunks a thread gathers per step
     constexpr int ZF_BYTES = CT * HC_NKK * 1024;
+    // weight fragments of groups [0, KREG) live in registers, the last HC_NKK - KREG in a per-wave LDS slab: with four row
+    // tiles per wave all 272 registers do not fit the 256 architectural ones, the compiler parks the overflow in the
+    // accumulator half and copies every such fragment back in front of its MFMA (four dependent v_accvgpr_read + a
+    // hazard nop per MFMA)
+    constexpr int KREG = WR > 2 ? 12 : HC_NKK;
+    constexpr int WL_WAVE = (HC_NKK - KREG) * WR * 1024;                   // bytes of LDS weight slab per wave
     static_assert(RT % NWR == 0 && WR % 2 == 0 && CT * KPM == 8, "cluster shape");
     extern __shared__ __attribute__((aligned(16))) char hsm[];
     char* Zf = hsm;                                // [tile][kk][lane][16 B]
@@ -78,7 +84,8 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     // ---- resident operands: the wave's WR row tiles x 17 groups of weight fragments live in REGISTERS for the whole
     // launch (136 or 272 of the 512 a lone wave per SIMD may hold): global row tile grt = c RT + vr WR + i of the 16x16x32
     // image, fragment (kk, grt) at (((grt / 4) NKK + kk) 4 + grt % 4) KB.  Only the state image is in LDS.
-    u32x4 areg[HC_NKK][WR];
+    u32x4 areg[KREG][WR];
+    char* wl = hsm + ZF_BYTES + (size_t)wave * WL_WAVE + lane16;             // this wave's slab: [kk - KREG][i][lane][16 B]
     {
         const char* src = reinterpret_cast<const char*>(p.packed_w) + p.w16_off + lane16;
 #pragma unroll
@@ -86,7 +93,9 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
 #pragma unroll
             for (int i = 0; i < WR; ++i) {
                 const int grt = c * RT + vr * WR + i;
-                areg[kk][i] = *reinterpret_cast<const u32x4*>(src + ((size_t)((grt >> 2) * HC_NKK + kk) * 4 + (grt & 3)) * 1024);
+                const u32x4 f = *reinterpret_cast<const u32x4*>(src + ((size_t)((grt >> 2) * HC_NKK + kk) * 4 + (grt & 3)) * 1024);
+                if (kk < KREG) areg[kk < KREG ? kk : 0][i] = f;
+                else *reinterpret_cast<u32x4*>(wl + (size_t)((kk - KREG) * WR + i) * 1024) = f;
             }
         for (int i = tid; i < ZF_BYTES / 16; i += HC_NT) reinterpret_cast<u32x4*>(Zf)[i] = u32x4{0, 0, 0, 0};   // X_0 = 0
     }
@@ -100,17 +109,19 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
             *reinterpret_cast<f64x2s*>(p.E + idx + 2) = f64x2s{(double)v2, (double)v3};
         }
     };
-    // ---- [U ; F] staging: thread (pilot f = tid & 63, chunk q = tid >> 6) builds the eight positions 8 q .. 8 q + 7
-    // of the [U ; F] group of its pilot: inputs row s + 1 scaled (pyESN.py:180-182), teacher row s scaled
-    const int sf = tid & (P - 1), sq = (tid / P) & 3;
-    const bool s_thr = tid < 4 * P;                                          // (C < 8: fewer staging threads than the block has)
+    // ---- [U ; F] staging: ALL 256 threads share the 32 positions x P pilots of the group: thread (pilot sf = tid % P,
+    // slice sq = tid / P) builds positions EPT sq .. EPT sq + EPT - 1 of its pilot (EPT = P / 8 = 2, 4 or 8 values: with
+    // 64 threads doing eight each, as the first version had it, the staging state alone took 96 registers of every lane):
+    // inputs row s + 1 scaled (pyESN.py:180-182), teacher row s scaled
+    constexpr int EPT = P / 8;
+    const int sf = tid & (P - 1), sq = tid / P;
     const int s_pil = pil0 + sf;
-    const bool s_ok = s_thr && s_pil < p.n_groups;
-    double uf_sc[8], uf_sh[8];
-    int uf_kind[8];                                                          // 0 = zero, 1 = input, 2 = teacher
+    const bool s_ok = s_pil < p.n_groups;
+    double uf_sc[EPT], uf_sh[EPT];
+    int uf_kind[EPT];                                                        // 0 = zero, 1 = input, 2 = teacher
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int pos = 8 * sq + e;
+    for (int e = 0; e < EPT; ++e) {
+        const int pos = EPT * sq + e;
         uf_kind[e] = 0; uf_sc[e] = 0.0; uf_sh[e] = 0.0;
         if (!s_ok) continue;
         if (pos < n_in) {
@@ -125,36 +136,37 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     }
     // raw operands of step s: input row s + 1, teacher row s.  Branch-free: every position has a base pointer and a
     // per-step stride (positions that hold nothing point at a valid address with stride 0 and are masked when staged)
-    const double* uf_ptr[8];
-    int uf_stride[8];
+    const double* uf_ptr[EPT];
+    int uf_stride[EPT];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int pos = 8 * sq + e;
+    for (int e = 0; e < EPT; ++e) {
+        const int pos = EPT * sq + e;
         uf_ptr[e] = p.U; uf_stride[e] = 0;
         if (uf_kind[e] == 1) { uf_ptr[e] = p.U + ((size_t)s_pil * p.T_in + 1) * n_in + pos; uf_stride[e] = n_in; }
         if (uf_kind[e] == 2) { uf_ptr[e] = p.D + (size_t)s_pil * (p.S + 1) * n_out + (pos - kin_p); uf_stride[e] = n_out; }
     }
-    auto fetch_uf = [&](int s, double (&raw)[8]) {
+    auto fetch_uf = [&](int s, double (&raw)[EPT]) {
         const int sc = s < p.S ? s : p.S - 1;                                // (past the end: any valid row, never staged)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) raw[e] = uf_ptr[e][(size_t)sc * uf_stride[e]];
+        for (int e = 0; e < EPT; ++e) raw[e] = uf_ptr[e][(size_t)sc * uf_stride[e]];
     };
     // scaled values -> the [U ; F] group of the pilot's tile; member 0 also writes the input columns of E row s + 1
-    auto stage_uf = [&](int s, const double (&raw)[8]) {
-        uint32_t out[4];
-        double sv[8];
+    auto stage_uf = [&](int s, const double (&raw)[EPT]) {
+        uint32_t out[EPT / 2];
+        double sv[EPT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sv[e] = uf_kind[e] ? raw[e] * uf_sc[e] + uf_sh[e] : 0.0;      // as the persistent kernel
+        for (int e = 0; e < EPT; ++e) sv[e] = uf_kind[e] ? raw[e] * uf_sc[e] + uf_sh[e] : 0.0;    // as the persistent kernel
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = TR::pack2((float)sv[2 * e], (float)sv[2 * e + 1]);
-        if (s_thr)
-            *reinterpret_cast<u32x4*>(Zf + ((size_t)((sf >> 4) * HC_NKK + 16) * 64 + sq * 16 + (sf & 15)) * 16) =
-                u32x4{out[0], out[1], out[2], out[3]};
-        if (c == 0 && s_ok && 8 * sq < n_in) {
-            const size_t e0 = ((size_t)s_pil * (p.S + 1) + (s + 1)) * ncols + n_res + 8 * sq;
+        for (int e = 0; e < EPT / 2; ++e) out[e] = TR::pack2((float)sv[2 * e], (float)sv[2 * e + 1]);
+        const int pos0 = EPT * sq;                                           // EPT divides 8: the slice stays inside one chunk
+        char* d = Zf + ((size_t)((sf >> 4) * HC_NKK + 16) * 64 + (pos0 >> 3) * 16 + (sf & 15)) * 16 + 2 * (pos0 & 7);
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (8 * sq + e < n_in) { if (p.E32) p.E32[e0 + e] = (float)sv[e]; else p.E[e0 + e] = sv[e]; }
+        for (int e = 0; e < EPT / 2; ++e) reinterpret_cast<uint32_t*>(d)[e] = out[e];
+        if (c == 0 && s_ok && pos0 < n_in) {
+            const size_t e0 = ((size_t)s_pil * (p.S + 1) + (s + 1)) * ncols + n_res + pos0;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (pos0 + e < n_in) { if (p.E32) p.E32[e0 + e] = (float)sv[e]; else p.E[e0 + e] = sv[e]; }
         }
     };
     if (c == 0 && s_ok && sq == 0) {                                         // E row 0 = [0, scale(u[0])]  (pyESN.py:179,189)
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
         }
     }
     __syncthreads();
-    double raw_cur[8], raw_nx[8];
+    double raw_cur[EPT], raw_nx[EPT];
     fetch_uf(0, raw_cur);
     stage_uf(0, raw_cur);
     fetch_uf(1, raw_cur);
@@ -274,10 +286,15 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
                 for (int n = 0; n < WC; ++n) bq[j][n] = *reinterpret_cast<const u32x4*>(zf_w + (size_t)(n * HC_NKK + j) * 1024);
 #pragma unroll
             for (int kk = 0; kk < HC_NKK; ++kk) {
+                u32x4 af[WR];
+#pragma unroll
+                for (int m = 0; m < WR; ++m)
+                    af[m] = kk < KREG ? areg[kk < KREG ? kk : 0][m]
+                                      : *reinterpret_cast<const u32x4*>(wl + (size_t)((kk - KREG) * WR + m) * 1024);
 #pragma unroll
                 for (int n = 0; n < WC; ++n)
 #pragma unroll
-                    for (int m = 0; m < WR; ++m) TR::mma16(acc[m][n], areg[kk][m], bq[kk & 3][n]);
+                    for (int m = 0; m < WR; ++m) TR::mma16(acc[m][n], af[m], bq[kk & 3][n]);
                 if (kk + 4 < HC_NKK) {
 #pragma unroll
                     for (int n = 0; n < WC; ++n)
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
         if (s + 1 == p.S) { store_rows(); break; }                           // (the last state is in E; nobody reads it back)
         stage_uf(s + 1, raw_cur);                                            // [U ; F] of step s + 1 (fetched one step ago)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) raw_cur[e] = raw_nx[e];
+        for (int e = 0; e < EPT; ++e) raw_cur[e] = raw_nx[e];
         if (!gather(s)) return;                                              // (ends with a workgroup barrier)
         HC_T(ht3)
         store_rows();
@@ -376,7 +393,8 @@ bool harvest_cluster_applies(int precision, const RecurParams& p) {
 
 template <typename TR, int C>
 static int launch_hc(const RecurParams& p, int n_clusters, unsigned long long* xch, hipStream_t stream) {
-    const size_t lds = (size_t)(C / 2) * HC_NKK * 1024;
+    // state image + (four row tiles per wave) the LDS slab of the last weight groups: see KREG in the kernel
+    const size_t lds = (size_t)(C / 2) * HC_NKK * 1024 + (C <= 4 ? (size_t)4 * (HC_NKK - 12) * 4 * 1024 : 0);
     const int grid = 8 * ((n_clusters + 7) / 8) * C;
     auto go = [&](auto kern) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
