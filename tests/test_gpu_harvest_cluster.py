@@ -1,6 +1,6 @@
-"""fp16 / bf16 harvest at 257..512 reservoir units on the LDS-resident cluster kernel (csrc/esn_harvest_cluster.hip:
-eight co-resident workgroups per 64 pilots keep the weight matrix in LDS and exchange their state slices through L2 as
-tagged granules) against the persistent harvest kernel (debug knob hcluster=0: same weights, same noise draws, only
+"""fp16 / bf16 harvest at 257..512 reservoir units on the cluster kernel (csrc/esn_harvest_cluster.hip: pairs of
+co-resident workgroups per 16 pilots keep the weight matrix in registers and exchange their state slices as tagged
+granules; clusters of 4 / 8 behind the knob) against the persistent harvest kernel (debug knob hcluster=0: same weights, same noise draws, only
 the summation order differs) and the CPU oracle: ragged pilot counts (partial clusters, a lone pilot, several clusters
 per XCD), the three noise modes, float32 and float64 extended states, reservoirs below the padded 512 rows."""
 import numpy as np
