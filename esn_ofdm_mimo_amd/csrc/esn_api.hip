@@ -37,7 +37,7 @@ bool mfma_geometry(int precision, int n_res, int n_in, int n_out, bool harvest, 
 int launch_recur_mfma(int precision, const RecurParams& p, hipStream_t stream);
 // esn_harvest_cluster.hip
 bool harvest_cluster_applies(int precision, const RecurParams& p);
-size_t harvest_cluster_workspace_bytes(int n_pilots, int C);
+size_t harvest_cluster_workspace_bytes(int n_pilots, int C, int n_wsets);
 int launch_harvest_cluster(int precision, const RecurParams& p, int C, void* workspace, hipStream_t stream);
 // esn_recur_skew16.hip
 int launch_recur_skew16(int precision, const RecurParams& p, hipStream_t stream);
@@ -406,7 +406,7 @@ size_t esn_harvest_workspace_bytes(int precision, const esn_shape_t* shape, int 
     p.harvest = 1; p.n_groups = n_groups; p.n_frames = n_groups; p.F = 1;
     if (knobs().cluster && cluster_applies(precision, p)) return cluster_workspace_bytes(p.n_res, p.n_in, p.n_out, true);
     if (knobs().hcluster && harvest_cluster_applies(precision, p))
-        return harvest_cluster_workspace_bytes(n_groups, knobs().hcluster == 1 ? 2 : knobs().hcluster);
+        return harvest_cluster_workspace_bytes(n_groups, knobs().hcluster == 1 ? 2 : knobs().hcluster, p.n_wsets);
     if (!big_harvest_applies(precision, p)) return 0;
     return big_harvest_workspace_bytes(n_groups, p.g.Kp);
 }
@@ -461,7 +461,7 @@ static int harvest_common(int precision, const esn_shape_t* shape, const void* p
     // 257..512 units, fp16/bf16, shared reservoir: clusters of eight workgroups with the matrix resident in LDS
     if (workspace && knobs().hcluster && harvest_cluster_applies(precision, p)) {
         const int hc_c = knobs().hcluster == 1 ? 2 : knobs().hcluster;           // members per cluster
-        const size_t need = harvest_cluster_workspace_bytes(n_groups, hc_c);
+        const size_t need = harvest_cluster_workspace_bytes(n_groups, hc_c, p.n_wsets);
         if (workspace_bytes < need)
             return fail(-1, "esn_harvest_batch: workspace holds %zu bytes, esn_harvest_workspace_bytes says %zu",
                         workspace_bytes, need);

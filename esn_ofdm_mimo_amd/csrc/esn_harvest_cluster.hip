@@ -33,9 +33,14 @@ constexpr int HC_NKK = 17;
 constexpr uint32_t HC_SPIN_LIMIT = 1u << 22;
 constexpr unsigned long long HC_TAGMASK = 0x4000400040004000ULL;
 
-static inline int hc_clusters(int n_pilots, int C) { return (n_pilots + 8 * C - 1) / (8 * C); }
-size_t harvest_cluster_workspace_bytes(int n_pilots, int C) {
-    return (size_t)hc_clusters(n_pilots, C) * 2 * C * 8 * 1024 + 64;        // two parities x C members x 8 KB, + error word
+// clusters: the pilots of one weight set (groups g with (g + rot) % n_wsets == w; all of them when the reservoir is
+// shared) are cut into runs of 8 C; cluster k serves set k % n_wsets, run k / n_wsets
+static inline int hc_clusters(int n_pilots, int C, int n_wsets) {
+    const int per_set = (n_pilots + n_wsets - 1) / n_wsets;
+    return n_wsets * ((per_set + 8 * C - 1) / (8 * C));
+}
+size_t harvest_cluster_workspace_bytes(int n_pilots, int C, int n_wsets) {
+    return (size_t)hc_clusters(n_pilots, C, n_wsets) * 2 * C * 8 * 1024 + 64;   // two parities x C members x 8 KB, + error word
 }
 
 __device__ __forceinline__ unsigned long long hc_tag_bits(int tag) {         // tag 1..15 -> bit 14 of each of four halves
@@ -77,6 +82,9 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
     const int cluster = xcd * cpx + li / C, c = li % C;
     if (cluster >= n_clusters) return;                                      // (a whole cluster leaves together)
+    const int nws = p.n_wsets;
+    const int ws = cluster % nws, kc = cluster / nws;                       // weight set of this cluster, run inside the set
+    const int gbase = (ws - p.wset_rot % nws + nws) % nws;                  // first group that uses set ws (group g: set (g + rot) % nws)
     unsigned int* err = reinterpret_cast<unsigned int*>(xch + (size_t)n_clusters * 2 * C * 1024);
     unsigned long long* xc = xch + (size_t)cluster * 2 * C * 1024;           // [parity][member][block][lane][2]
     if (tid == 0) sh_dead = 0;
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     u32x4 areg[KREG][WR];
     char* wl = hsm + ZF_BYTES + (size_t)wave * WL_WAVE + lane16;             // this wave's slab: [kk - KREG][i][lane][16 B]
     {
-        const char* src = reinterpret_cast<const char*>(p.packed_w) + p.w16_off + lane16;
+        const char* src = reinterpret_cast<const char*>(p.packed_w) + (size_t)ws * p.wset_stride + p.w16_off + lane16;
 #pragma unroll
         for (int kk = 0; kk < HC_NKK; ++kk)
 #pragma unroll
@@ -99,7 +107,11 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
             }
         for (int i = tid; i < ZF_BYTES / 16; i += HC_NT) reinterpret_cast<u32x4*>(Zf)[i] = u32x4{0, 0, 0, 0};   // X_0 = 0
     }
-    const int pil0 = cluster * P;
+    // pilot (= group = frame) index of the cluster's f-th pilot: the run's f-th group of weight set ws (-1 past the end)
+    auto pilot_of = [&](int f) -> int {
+        const int gi = gbase + (kc * P + f) * nws;
+        return gi < p.n_groups ? gi : -1;
+    };
     auto store_E4 = [&](size_t idx, float v0, float v1, float v2, float v3) {      // idx multiple of 4
         if (p.E32) {
             *reinterpret_cast<f32x4*>(p.E32 + idx) = f32x4{v0, v1, v2, v3};
@@ -115,8 +127,8 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     // inputs row s + 1 scaled (pyESN.py:180-182), teacher row s scaled
     constexpr int EPT = P / 8;
     const int sf = tid & (P - 1), sq = tid / P;
-    const int s_pil = pil0 + sf;
-    const bool s_ok = s_pil < p.n_groups;
+    const int s_pil = pilot_of(sf);
+    const bool s_ok = s_pil >= 0;
     double uf_sc[EPT], uf_sh[EPT];
     int uf_kind[EPT];                                                        // 0 = zero, 1 = input, 2 = teacher
 #pragma unroll
@@ -195,8 +207,8 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
     uint32_t key1[WC];
 #pragma unroll
     for (int n = 0; n < WC; ++n) {
-        const int pl = pil0 + (vc * WC + n) * 16 + col;
-        fr2[n] = pl < p.n_groups ? pl : -1;
+        const int pl = pilot_of((vc * WC + n) * 16 + col);
+        fr2[n] = pl;
         key1[n] = mix32((uint32_t)p.seed ^ (((uint32_t)pl + p.frame_off) * 0x9E3779B9U));
     }
     const uint32_t seed_hi = (uint32_t)(p.seed >> 32);
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
 }
 
 bool harvest_cluster_applies(int precision, const RecurParams& p) {
-    return (precision == ESN_F16 || precision == ESN_BF16) && p.harvest && p.g.s16 && p.n_wsets == 1 && p.F == 1 &&
+    return (precision == ESN_F16 || precision == ESN_BF16) && p.harvest && p.g.s16 && p.F == 1 &&
            p.n_groups >= 1 && (p.n_res % 4) == 0 && (p.n_res + p.n_in) % 4 == 0;
 }
 
@@ -411,8 +423,8 @@ static int launch_hc(const RecurParams& p, int n_clusters, unsigned long long* x
 
 // C = members per cluster: 2 (default), 4 or 8
 int launch_harvest_cluster(int precision, const RecurParams& p, int C, void* workspace, hipStream_t stream) {
-    const int n_clusters = hc_clusters(p.n_groups, C);
-    hipError_t e = hipMemsetAsync(workspace, 0, harvest_cluster_workspace_bytes(p.n_groups, C), stream);   // tags start at 1
+    const int n_clusters = hc_clusters(p.n_groups, C, p.n_wsets);
+    hipError_t e = hipMemsetAsync(workspace, 0, harvest_cluster_workspace_bytes(p.n_groups, C, p.n_wsets), stream);   // tags start at 1
     if (e != hipSuccess) return (int)e;
     unsigned long long* xch = reinterpret_cast<unsigned long long*>(workspace);
 #define HC_CASE(TRv, Cv) if (C == Cv) return launch_hc<TRv, Cv>(p, n_clusters, xch, stream);

@@ -98,3 +98,34 @@ def test_cluster_harvest_bf16_and_fit(mods):
     want = d[:, tr:] * 0.8
     assert rel_err(pred, want) < 1e-6
     assert rel_err(w_out.cpu().numpy(), w_ref.cpu().numpy()) < 0.5
+
+
+def test_cluster_harvest_with_several_weight_sets(mods):
+    """One reservoir per coherence block (a pool of weight sets, group g -> set (group_offset + g) % n_wsets): every cluster
+    serves ONE set, its pilots are that set's groups in order.  Same states as the persistent kernel, whatever the rotation."""
+    batched, L = mods
+    rs = np.random.RandomState(17)
+    n_in, n_out, n_res, t, G, nws = 16, 8, 512, 25, 45, 3
+    ws = [eo.draw_weights(rs, n_in, n_out, n_res, 0.9, 0.1) for _ in range(nws)]
+    w, w_in, w_fb = (np.stack([x[i] for x in ws]) for i in range(3))
+    bank = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=1e-3)
+    bank.set_scaling(rs.rand(G, n_in) * 0.2 + 0.1, None, rs.rand(G, n_out) + 0.5, None)
+    u, d = rs.randn(G, t, n_in), np.tanh(rs.randn(G, t, n_out))
+    for off in (0, 5):
+        kw = dict(precision="f16", noise_mode="counter", seed=8, group_offset=off)
+        e = bank.harvest(u, d, **kw).cpu().numpy()
+        bank.raise_if_harvest_timed_out()
+        L.debug_set("hcluster", "0")
+        try:
+            ref = bank.harvest(u, d, **kw).cpu().numpy()
+        finally:
+            L.debug_set("hcluster", "1")
+        assert np.array_equal(e[..., n_res:], ref[..., n_res:])
+        assert rel_err(e[..., :n_res], ref[..., :n_res]) < 4e-3
+    # noise-free against the oracle, group by group with ITS weight set
+    bank0 = batched.ReservoirBank(n_in, n_out, n_res, w, w_in, w_fb, noise=0.0)
+    e0 = bank0.harvest(u, d, precision="f16", noise_mode="none", group_offset=5).cpu().numpy()
+    for g in (0, 1, 2, 44):
+        o = eo.OracleESN(n_in, n_out, n_res, noise=0.0, random_state=1, weights=ws[(5 + g) % nws])
+        o.fit(u[g], d[g], 0)
+        assert rel_err(e0[g], o._ext_states) < 2e-2, (g, rel_err(e0[g], o._ext_states))
