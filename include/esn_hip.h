@@ -182,7 +182,7 @@ int esn_predict_batch(int precision, const esn_shape_t* shape,
  *   E is 16-byte aligned.
  *   workspace: device scratch of esn_harvest_workspace_bytes(...) bytes, or NULL.  Three shapes use it: reservoirs
  *   beyond 1024 units in fp16/bf16 (one tiled GEMM launch per timestep, 128 x 64 tiles: a fit has one sequence per
- *   trained ESN, so the tile is cut for workgroup count); fp16/bf16 at 257..512 units with a shared reservoir (pairs
+ *   trained ESN, so the tile is cut for workgroup count); fp16/bf16 at 257..512 units (pairs
  *   of co-resident workgroups keep the weight matrix in registers and exchange their state slices through the
  *   workspace every step, esn_harvest_cluster.hip; its last 64 bytes hold an error word that is non-zero if a
  *   workgroup timed out waiting for its peer: the states are then invalid); and ONE float64 sequence (the cluster
