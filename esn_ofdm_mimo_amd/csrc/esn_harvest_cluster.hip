@@ -274,7 +274,7 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
 
     const char* zf_w = Zf + (size_t)(vc * WC) * HC_NKK * 1024 + lane16;        // the wave's pilot tiles
 #ifdef ESN_STAMPS
-    unsigned long long hst[4] = {0, 0, 0, 0};
+    unsigned long long hst[6] = {0, 0, 0, 0, 0, 0}, ht_prev = 0;
 #define HC_T(v) const unsigned long long v = __builtin_amdgcn_s_memrealtime();
 #else
 #define HC_T(v)
@@ -389,12 +389,17 @@ __global__ __launch_bounds__(HC_NT) void harvest_cluster_kernel(RecurParams p, i
         HC_T(ht3)
         store_rows();
 #ifdef ESN_STAMPS
-        hst[0] += ht1 - ht0; hst[1] += ht2 - ht1; hst[2] += ht3 - ht2; hst[3] += hc_polls;
+        {
+            const unsigned long long ht4 = __builtin_amdgcn_s_memrealtime();
+            hst[0] += ht1 - ht0; hst[1] += ht2 - ht1; hst[2] += ht3 - ht2; hst[3] += hc_polls; hst[4] += ht4 - ht3;
+            if (s > 0) hst[5] += ht0 - ht_prev;                    // loop back-edge: end of the previous step -> top of this one
+            ht_prev = ht4;
+        }
 #endif
     }
 #ifdef ESN_STAMPS
     if (p.stamps && blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 4; ++i) p.stamps[wave * 8 + i] = hst[i];
+        for (int i = 0; i < 6; ++i) p.stamps[wave * 8 + i] = hst[i];
 #endif
 }
 

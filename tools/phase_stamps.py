@@ -39,10 +39,10 @@ if len(sys.argv) > 3 and sys.argv[3] == "harvest":      # stamps of the last har
     Th = params.t_frame + params.delay
     if raw[4:8, :7].sum() == 0:       # the 4-wave cluster kernel (esn_harvest_cluster.hip): 10 ns ticks and poll rounds
         print("harvest cluster kernel, workgroup 0: microseconds per timestep and poll rounds per gather, per wave")
-        print("wave   fetch+GEMM   E+publish   stage+gather   poll rounds")
+        print("wave   fetch+GEMM   E+publish   stage+gather   poll rounds   E-row stores   loop edge")
         for w in range(4):
-            v = raw[w, :4].astype(float) / Th
-            print(f"{w:4d} {v[0] / 100:12.2f} {v[1] / 100:11.2f} {v[2] / 100:14.2f} {v[3]:13.2f}")
+            v = raw[w, :6].astype(float) / Th
+            print(f"{w:4d} {v[0] / 100:12.2f} {v[1] / 100:11.2f} {v[2] / 100:14.2f} {v[3]:13.2f} {v[4] / 100:14.2f} {v[5] / 100:11.2f}")
         sys.exit(0)
     names = ["G gemm", "-", "-", "wait", "E + staging", "wait", "E-row copy"]
     print("harvest: cycles per timestep (workgroup 0), per wave")
