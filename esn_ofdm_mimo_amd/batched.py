@@ -244,6 +244,11 @@ class ReservoirBank:
         E = self.harvest(U, D, precision, noise_mode, noise_u, seed, e_dtype=e_dtype, group_offset=group_offset)
         W_out, status = self.solve(E, D, transient, method=method)
         self.set_readout(W_out)
+        ht = getattr(self, "harvest_timeout", None)
+        if ht is not None:
+            # a harvest cluster that timed out waiting for its peer left invalid states: every group's status says so
+            # (-9; device-side, no host sync here -- whoever reads fit_status sees it)
+            status = self.torch.where(ht.ne(0).expand_as(status), self.torch.full_like(status, -9), status)
         self.fit_status = status
         return E
 
