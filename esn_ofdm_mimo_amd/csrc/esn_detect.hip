@@ -30,6 +30,19 @@ __global__ __launch_bounds__(1024) void detect_count_kernel(DetectParams dp) {
     const int group = frame / dp.frames_per_group;
     const double2* y = reinterpret_cast<const double2*>(dp.Y) + (size_t)frame * N * n_t;
 
+    // transmitted bits of the elements this thread will slice (the m x n_t bytes of a subcarrier are contiguous), fetched
+    // NOW: the slicer at the end would otherwise pay a second global round trip behind the FFT
+    constexpr int TXP = 4;                                   // elements prefetched per thread (N na / nthr at the benchmark shape)
+    const bool tx_pre = dp.m == 4 && n_t == 4 && na == n_t && N * na <= TXP * nthr && ((uintptr_t)dp.tx_bits & 15) == 0;
+    uint4 txw[TXP];
+    if (tx_pre) {
+#pragma unroll
+        for (int q = 0; q < TXP; ++q) {
+            const int e = tid + q * nthr, k = e / na;
+            txw[q] = (e < N * na) ? *reinterpret_cast<const uint4*>(dp.tx_bits + ((size_t)frame * N + k) * 16) : uint4{0, 0, 0, 0};
+        }
+    }
+    const double p_i_g = dp.p_i[group];
     for (int k = tid; k < half; k += nthr) {
         double sn, cs;
         sincospi(-2.0 * (double)k / (double)N, &sn, &cs);
@@ -82,7 +95,7 @@ __global__ __launch_bounds__(1024) void detect_count_kernel(DetectParams dp) {
 
     const int side = 1 << (dp.m / 2);
     const double norm = sqrt(2.0 * (double)(side * side - 1) / 3.0);
-    const double scale = 1.0 / ((double)N * sqrt(dp.p_i[group]));
+    const double scale = 1.0 / ((double)N * sqrt(p_i_g));
     int errs = 0;
     for (int e = tid; e < N * na; e += nthr) {               // element e = (subcarrier k, antenna), antenna fastest
         const int k = e / na, ant = a0 + e - k * na;
@@ -95,8 +108,18 @@ __global__ __launch_bounds__(1024) void detect_count_kernel(DetectParams dp) {
         i = min(max(i, 0), side - 1);
         j = min(max(j, 0), side - 1);
         const int idx = i * side + j;
-        const uint8_t* tb = dp.tx_bits + ((size_t)frame * N + k) * dp.m * n_t + ant;
-        for (int bb = 0; bb < dp.m; ++bb) errs += (((idx >> bb) & 1) != (int)tb[(size_t)bb * n_t]);
+        if (tx_pre) {                                        // byte bb n_t + ant of the subcarrier's 16
+            const int q = (e - tid) / nthr;
+            uint4 w = txw[0];
+#pragma unroll
+            for (int qq = 1; qq < TXP; ++qq) if (q == qq) w = txw[qq];
+            const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) errs += (int)(((uint32_t)(idx >> bb) & 1u) != ((wd[bb] >> (8 * ant)) & 0xffu));
+        } else {
+            const uint8_t* tb = dp.tx_bits + ((size_t)frame * N + k) * dp.m * n_t + ant;
+            for (int bb = 0; bb < dp.m; ++bb) errs += (((idx >> bb) & 1) != (int)tb[(size_t)bb * n_t]);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) errs += __shfl_down(errs, off);
