@@ -315,8 +315,12 @@ class DetectorSweep:
         torch, p = self.torch, self.p
         d = p.delay
         g, t = pilot_y.shape[0], pilot_y.shape[1]
-        U = torch.zeros((g, t + d, self.n_in), dtype=torch.float64, device=self.device)
-        D = torch.zeros((g, t + d, self.n_out), dtype=torch.float64, device=self.device)
+        # zero-padded pilot buffers are kept between calls of the same shape (the padding rows are never written)
+        io = getattr(self, "_train_bufs", None)
+        if io is None or io[0].shape != (g, t + d, self.n_in):
+            io = self._train_bufs = (torch.zeros((g, t + d, self.n_in), dtype=torch.float64, device=self.device),
+                                     torch.zeros((g, t + d, self.n_out), dtype=torch.float64, device=self.device))
+        U, D = io
         U[:, :t] = _view_real(pilot_y)
         D[:, d:d + t] = _view_real(pilot_x)
         self._fit_io = (U, D, p.forget)
